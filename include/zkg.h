@@ -1,0 +1,151 @@
+/*
+ * zkg.h — C ABI of the MI355X-native Groth16 prover hot path (alt_bn128).
+ *
+ * This is the drop-in boundary below zklaim's prover call
+ *     r1cs_gg_ppzksnark_prover<ppT>(proving_key, primary_input, auxiliary_input)
+ * at /root/reference/zklaim/snark.cpp:126 (reached from libsnark_prove,
+ * zklaim/libsnark_wrapper.cpp:218-249, reached from zklaim_proof_generate,
+ * zklaim/zklaim.c:77-80).  Everything above that call stays host C/C++; everything
+ * below it is hand-written HIP for gfx950 behind the functions declared here.
+ * Each entry point names the libsnark / libff / libfqfft function it replaces; those
+ * live in the un-vendored submodule lib/libsnark (.gitmodules:1-6) and are cited by
+ * the reference call site that reaches them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; never throws; 0 == success
+ *     (ZKLAIM_OK, zklaim/zklaim.h:38), non-zero == failure (ZKLAIM_ERROR semantics).
+ *   - Field element (Fq or Fr): 4 x uint64_t little-endian limbs, MONTGOMERY form with
+ *     R = 2^256 — the in-memory form of libff's Fp_model<4,...> — unless a parameter
+ *     says "canonical".
+ *   - G1 affine: 8 limbs  X||Y.   G2 affine: 16 limbs  X.c0||X.c1||Y.c0||Y.c1.
+ *     The point at infinity is encoded as all-zero limbs ((0,0) is not on either curve).
+ *   - "jac" outputs: X||Y||Z, NORMALISED (Z == Montgomery one) or infinity == (0, one, 0),
+ *     i.e. what libff's to_affine_coordinates() leaves behind.  Normalised output is what
+ *     makes results byte-comparable between the HIP path and the CPU oracle.
+ *   - *_dev entry points take DEVICE pointers (hipMalloc'd, or torch tensor data_ptr())
+ *     and a hipStream_t passed as void*; all others take HOST pointers and stage
+ *     internally.
+ */
+#ifndef ZKG_H
+#define ZKG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKG_OK 0
+#define ZKG_ERROR 1          /* generic failure (bad argument, HIP error)            */
+#define ZKG_UNSATISFIED 1    /* libsnark_prove returns 1 on an unsatisfied system
+                                (zklaim/libsnark_wrapper.cpp:233-240)                */
+#define ZKG_PROOF_BYTES 134  /* G1(34) || G2(66) || G1(34), see zkg_groth16_prove    */
+
+/* ---- R1CS in CSR form (three matrices).  Column 0 is the constant ONE, columns
+ *      1..num_inputs the primary input, the rest the auxiliary input: the layout of
+ *      libsnark's r1cs_constraint_system + variable indices (used through
+ *      pb.get_constraint_system(), snark.cpp:87).                                    */
+typedef struct zkg_r1cs {
+    uint32_t num_variables;    /* n, excluding the constant                           */
+    uint32_t num_inputs;       /* l                                                   */
+    uint32_t num_constraints;  /* C                                                   */
+    uint32_t reserved;
+    const uint32_t *a_rowptr, *a_col; const uint64_t *a_val;   /* rowptr[C+1], col[nnz], val[nnz*4] (Fr) */
+    const uint32_t *b_rowptr, *b_col; const uint64_t *b_val;
+    const uint32_t *c_rowptr, *c_col; const uint64_t *c_val;
+} zkg_r1cs;
+
+/* ---- Proving key material as flat host arrays: the fields of
+ *      r1cs_gg_ppzksnark_proving_key<ppT> (imported at libsnark_wrapper.cpp:160-168).
+ *      B_query is libsnark's sparse knowledge_commitment_vector<G2,G1> densified:
+ *      absent entries are infinity.                                                   */
+typedef struct zkg_pk {
+    zkg_r1cs cs;               /* the (possibly A/B-swapped) system stored in the pk   */
+    uint32_t log_m;            /* evaluation domain size m = 2^log_m                   */
+    uint32_t reserved;
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1;   /* 8 limbs each                   */
+    const uint64_t *beta_g2, *delta_g2;              /* 16 limbs each                  */
+    const uint64_t *A_query;   /* (n+1) x 8                                            */
+    const uint64_t *B_g1;      /* (n+1) x 8                                            */
+    const uint64_t *B_g2;      /* (n+1) x 16                                           */
+    const uint64_t *H_query;   /* (m-1) x 8                                            */
+    const uint64_t *L_query;   /* (n-l) x 8                                            */
+} zkg_pk;
+
+typedef struct zkg_crs zkg_crs;   /* opaque: device-resident proving key + domain tables */
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+/* Replaces ppT::init_public_params() (libsnark_wrapper.cpp:204,227,259).  Selects HIP
+ * device `device` (>=0) for the calling process (one process per GPU), uploads constant
+ * tables.  Re-entrant; fails (non-zero) if no HIP device is usable — there is no CPU
+ * fallback behind this ABI.                                                            */
+int  zkg_init(int device);
+void zkg_shutdown(void);
+const char *zkg_last_error(void);
+/* number of compute units / device name of the device zkg_init selected (diagnostics) */
+int  zkg_device_info(char *name, size_t name_len, int *compute_units);
+
+/* ---- NTT: libfqfft basic_radix2_domain<Fr>::FFT / iFFT / cosetFFT / icosetFFT
+ *      (reached from r1cs_to_qap_witness_map inside the call at snark.cpp:126).
+ *      a: N = 2^logN Fr elements, Montgomery, natural order in and out, in place.
+ *      inverse: 0 forward, 1 inverse (includes the 1/N scaling).
+ *      coset:   0 plain, 1 coset with g = Fr::multiplicative_generator (= 5).         */
+int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset);
+int zkg_ntt_dev(void *d_a, unsigned logN, int inverse, int coset, void *stream);
+
+/* ---- MSM: libff::multi_exp<G1,Fr,multi_exp_method_BDLO12> and
+ *      multi_exp_with_mixed_addition (A/H/L queries), and the G2 half of
+ *      kc_multi_exp_with_mixed_addition (B query); reached from snark.cpp:126.
+ *      bases: affine Montgomery; scalars: N x 4 limbs, CANONICAL (as_bigint()) values
+ *      in [0, r).  out: normalised jac.                                               */
+int zkg_msm_g1(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[12]);
+int zkg_msm_g2(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[24]);
+/* device-resident inputs; scalars_mont != 0 means the scalars are Montgomery Fr (a
+ * witness vector) and are converted on the fly.  The result is written to HOST memory
+ * (out_jac) after the stream is synchronised.                                         */
+int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
+                   uint64_t out_jac[12], void *stream);
+int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
+                   uint64_t out_jac[24], void *stream);
+/* Sum of `count` normalised-jac G1 (G2) points held in HOST memory: the combine step after
+ * the per-GPU partial MSMs have been all-gathered (RCCL has no elliptic-curve reduce op). */
+int zkg_g1_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[12]);
+int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]);
+
+/* ---- fixed-base batch: out[i] = scalars[i] * base (affine out).  The batch_exp of
+ *      libsnark's generator (snark.cpp:91); used here to build synthetic bases on device. */
+int zkg_g1_fixed_base_dev(const uint64_t base[8], const void *d_scalars, size_t n, void *d_out_affine, void *stream);
+int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t n, void *d_out_affine, void *stream);
+
+/* ---- CRS residency: parse once, keep on device (removes the per-call pk re-parse of
+ *      libsnark_wrapper.cpp:230 and the by-value pk copy of snark.cpp:107-109).        */
+zkg_crs *zkg_crs_upload(const zkg_pk *pk);
+void     zkg_crs_free(zkg_crs *crs);
+
+/* ---- Groth16 prove: r1cs_gg_ppzksnark_prover (snark.cpp:126) with the prover
+ *      randomness (r, s) as explicit inputs (libsnark draws them internally).
+ *      witness: n x 4 limbs Montgomery Fr = primary_input || auxiliary_input.
+ *      r, s: Montgomery Fr.  proof_out: >= ZKG_PROOF_BYTES; layout = libsnark
+ *      operator<<(proof) under its default flags (binary, Montgomery, compressed):
+ *      g_A (34 B) || g_B (66 B) || g_C (34 B) (exported at libsnark_wrapper.cpp:170-181).
+ *      check_satisfied != 0 reproduces the gate of snark.cpp:121-124 and returns
+ *      ZKG_UNSATISFIED without proving.                                                */
+int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_t r[4],
+                      const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
+/* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */
+int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_out);
+/* per-stage device milliseconds of the last zkg_groth16_prove on this crs:
+ * [0] R1CS mat-vec, [1] 7 NTTs + pointwise, [2] MSM A, [3] MSM B(G1), [4] MSM B(G2),
+ * [5] MSM H, [6] MSM L, [7] total                                                      */
+int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
+
+/* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
+ * average device ms per launch of the dominant kernel over the calls since the last reset */
+void  zkg_timing_reset(void);
+float zkg_timing_dominant_ms(int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKG_H */
