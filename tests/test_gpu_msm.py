@@ -1,0 +1,90 @@
+"""GPU parity: zkg_msm_g1 / zkg_msm_g2 (HIP Pippenger) vs golden vectors and the oracle's BDLO12 restatement.  Bit-exact
+on the normalised result."""
+import numpy as np
+import pytest
+
+from gpu_util import dev_bases_g1, zkg  # noqa: F401
+from util import R, arr, g1_aff, g1_jac_expected, g2_aff, g2_jac_expected, golden, h, limbs, random_fr_canonical
+
+pytestmark = pytest.mark.gpu
+
+
+def test_msm_golden(zkg):
+    g = golden("msm.json")
+    for c in g["g1"]:
+        n = len(c["bases"])
+        bases = np.array([g1_aff(b) for b in c["bases"]], np.uint64).reshape(n, 8)
+        sc = arr([h(s) for s in c["scalars"]]) if n else np.zeros((0, 4), np.uint64)
+        assert np.array_equal(zkg.msm_g1(bases, sc), g1_jac_expected(c["result"])), c["tag"]
+    for c in g["g2"]:
+        n = len(c["bases"])
+        bases = np.array([g2_aff(b) for b in c["bases"]], np.uint64).reshape(n, 16)
+        sc = arr([h(s) for s in c["scalars"]])
+        assert np.array_equal(zkg.msm_g2(bases, sc), g2_jac_expected(c["result"])), c["tag"]
+
+
+def test_fixed_base_matches_oracle(zkg, oracle):
+    _, bases, ks = dev_bases_g1(zkg, 300, 0x1234)
+    exp = oracle.g1_fixed_base(oracle.g1_generator(), ks)
+    assert np.array_equal(bases, exp)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4096, 20000])
+def test_msm_g1_vs_oracle(zkg, oracle, n):
+    _, bases, _ = dev_bases_g1(zkg, n, 0x5A4B4C41494D0001 + n)
+    sc = random_fr_canonical(n, 0x5A4B4C41494D0002 + n)
+    assert np.array_equal(zkg.msm_g1(bases, sc), oracle.msm_g1(bases, sc))
+
+
+def test_msm_g1_bit_scalars_and_edges(zkg, oracle):
+    """zklaim-shaped scalars: mostly 0/1 (multi_exp_with_mixed_addition's shortcut), plus r-1, duplicates, infinity bases."""
+    n = 5000
+    _, bases, _ = dev_bases_g1(zkg, n, 77)
+    sc = random_fr_canonical(n, 78)
+    rng = np.random.default_rng(5)
+    kind = rng.integers(0, 100, n)
+    sc[kind < 50] = 0
+    sc[(kind >= 50) & (kind < 95), :] = np.array([1, 0, 0, 0], np.uint64)
+    sc[4000] = limbs(R - 1); sc[4001] = limbs(R - 1)
+    bases[4001] = bases[4000]                 # duplicate base, same scalar -> doubling path inside a bucket
+    bases[4002] = 0                           # base at infinity
+    bases[10] = bases[11]; sc[10] = sc[11] = np.array([1, 0, 0, 0], np.uint64)      # doubling inside the ones-sum
+    assert np.array_equal(zkg.msm_g1(bases, sc), oracle.msm_g1(bases, sc, oracle.MIXED))
+
+
+def test_msm_g2_vs_oracle(zkg, oracle):
+    n = 600
+    ks = random_fr_canonical(n, 99)
+    bases = oracle.g2_fixed_base(oracle.g2_generator(), ks)
+    sc = random_fr_canonical(n, 100)
+    sc[:100] = 0; sc[100:300] = np.array([1, 0, 0, 0], np.uint64)
+    assert np.array_equal(zkg.msm_g2(bases, sc), oracle.msm_g2(bases, sc, oracle.MIXED))
+
+
+def test_msm_full_size_properties(zkg, oracle):
+    """BASELINE config 2 size (2^20 points): linearity in the scalars and a split/sum identity, checked through the
+    device-pointer entry points with bases resident; a 2^16 prefix is checked against the oracle directly."""
+    import torch
+    n = 1 << 20
+    d_bases, bases, _ = dev_bases_g1(zkg, n, 0x5A4B4C41494D0001)
+    sc = random_fr_canonical(n, 0x5A4B4C41494D0002)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    full = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)
+    # split: MSM(all) == MSM(first half) + MSM(second half)
+    half = n // 2
+    p0 = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), half)
+    p1 = zkg.msm_g1_dev(d_bases[half:].data_ptr(), d_sc[half:].data_ptr(), n - half)
+    assert np.array_equal(zkg.g1_sum(np.concatenate([p0, p1])), full)
+    assert np.array_equal(oracle.g1_sum(np.concatenate([p0, p1])), full)
+    # scalars all equal to s: sum s*P_i == s * (sum P_i)
+    ones = np.zeros((n, 4), np.uint64); ones[:, 0] = 1
+    d_ones = torch.from_numpy(ones.view(np.int64)).cuda()
+    total = zkg.msm_g1_dev(d_bases.data_ptr(), d_ones.data_ptr(), n)
+    k = 1 << 16
+    assert np.array_equal(zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), k), oracle.msm_g1(bases[:k], sc[:k]))
+    s = sc[0]; k2 = 2048
+    same = np.tile(s, (k2, 1)); d_same = torch.from_numpy(np.ascontiguousarray(same).view(np.int64)).cuda()
+    psum = zkg.msm_g1_dev(d_bases.data_ptr(), d_ones.data_ptr(), k2)
+    lhs = zkg.msm_g1_dev(d_bases.data_ptr(), d_same.data_ptr(), k2)
+    assert np.array_equal(lhs, oracle.g1_scalar_mul(psum[:8], s))
+    assert total.any()

@@ -1,0 +1,220 @@
+"""ctypes binding of include/zkg.h (the drop-in boundary below snark.cpp:126 of the reference).
+
+Array conventions are those of zkg.h: numpy uint64 arrays of little-endian limbs, Montgomery form
+unless stated, G1 affine 8 limbs, G2 affine 16 limbs, normalised "jac" outputs 12 / 24 limbs.
+*_dev functions take raw device pointers (e.g. ``torch.Tensor.data_ptr()``) and a HIP stream handle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libzkg.so")
+
+DECLARED_SYMBOLS = [
+    "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_msm_g1", "zkg_msm_g2",
+    "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
+    "zkg_crs_upload", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
+    "zkg_timing_dominant_ms",
+]
+
+
+class ZkgError(RuntimeError):
+    pass
+
+
+class R1CS(C.Structure):
+    _fields_ = [("num_variables", C.c_uint32), ("num_inputs", C.c_uint32), ("num_constraints", C.c_uint32), ("reserved", C.c_uint32)] + \
+        [(f"{m}_{f}", C.c_void_p) for m in "abc" for f in ("rowptr", "col", "val")]
+
+
+class PK(C.Structure):
+    _fields_ = [("cs", R1CS), ("log_m", C.c_uint32), ("reserved", C.c_uint32)] + \
+        [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query")]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libzkg.so.  Fails loudly when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ZkgError(f"{_SO} is missing: build it with `python -m zklaim_amd.build` (hipcc, gfx950)")
+        _lib = C.CDLL(_SO)
+        _lib.zkg_last_error.restype = C.c_char_p
+        _lib.zkg_timing_dominant_ms.restype = C.c_float
+        _lib.zkg_crs_upload.restype = C.c_void_p
+        _lib.zkg_crs_upload.argtypes = [C.c_void_p]
+        _lib.zkg_crs_free.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ZkgError(f"{what} failed (rc={rc}): {lib().zkg_last_error().decode()}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _vp(x):
+    return C.c_void_p(int(x) if x else 0)
+
+
+_initialised = False
+
+
+def init(device=0):
+    global _initialised
+    _check(lib().zkg_init(int(device)), "zkg_init")
+    _initialised = True
+
+
+def shutdown():
+    global _initialised
+    if _initialised:
+        lib().zkg_shutdown()
+    _initialised = False
+
+
+def device_info():
+    name = C.create_string_buffer(128); cus = C.c_int(0)
+    _check(lib().zkg_device_info(name, C.c_size_t(128), C.byref(cus)), "zkg_device_info")
+    return name.value.decode(), cus.value
+
+
+# ---- NTT (libfqfft basic_radix2_domain FFT/iFFT/cosetFFT/icosetFFT) -------------------------------
+def ntt(a, inverse=False, coset=False):
+    a = _u64(a).copy(); n = a.size // 4
+    logn = n.bit_length() - 1
+    if n == 0 or (1 << logn) != n:
+        raise ZkgError("ntt: length must be a power of two")
+    _check(lib().zkg_ntt(_p(a), C.c_uint(logn), int(inverse), int(coset)), "zkg_ntt")
+    return a.reshape(n, 4)
+
+
+def ntt_dev(d_ptr, logn, inverse=False, coset=False, stream=0):
+    _check(lib().zkg_ntt_dev(_vp(d_ptr), C.c_uint(logn), int(inverse), int(coset), _vp(stream)), "zkg_ntt_dev")
+
+
+# ---- MSM (libff multi_exp / multi_exp_with_mixed_addition) -----------------------------------------
+def msm_g1(bases, scalars):
+    bases = _u64(bases); scalars = _u64(scalars); out = np.zeros(12, np.uint64)
+    _check(lib().zkg_msm_g1(_p(bases), _p(scalars), C.c_size_t(scalars.size // 4), _p(out)), "zkg_msm_g1")
+    return out
+
+
+def msm_g2(bases, scalars):
+    bases = _u64(bases); scalars = _u64(scalars); out = np.zeros(24, np.uint64)
+    _check(lib().zkg_msm_g2(_p(bases), _p(scalars), C.c_size_t(scalars.size // 4), _p(out)), "zkg_msm_g2")
+    return out
+
+
+def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0):
+    out = np.zeros(12, np.uint64)
+    _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), int(scalars_mont), _p(out), _vp(stream)), "zkg_msm_g1_dev")
+    return out
+
+
+def msm_g2_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0):
+    out = np.zeros(24, np.uint64)
+    _check(lib().zkg_msm_g2_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), int(scalars_mont), _p(out), _vp(stream)), "zkg_msm_g2_dev")
+    return out
+
+
+def g1_sum(points_jac):
+    pts = _u64(points_jac); out = np.zeros(12, np.uint64)
+    _check(lib().zkg_g1_sum(_p(pts), C.c_size_t(pts.size // 12), _p(out)), "zkg_g1_sum")
+    return out
+
+
+def g2_sum(points_jac):
+    pts = _u64(points_jac); out = np.zeros(24, np.uint64)
+    _check(lib().zkg_g2_sum(_p(pts), C.c_size_t(pts.size // 24), _p(out)), "zkg_g2_sum")
+    return out
+
+
+def fixed_base_g1_dev(base, d_scalars, n, d_out, stream=0):
+    base = _u64(base)
+    _check(lib().zkg_g1_fixed_base_dev(_p(base), _vp(d_scalars), C.c_size_t(n), _vp(d_out), _vp(stream)), "zkg_g1_fixed_base_dev")
+
+
+def fixed_base_g2_dev(base, d_scalars, n, d_out, stream=0):
+    base = _u64(base)
+    _check(lib().zkg_g2_fixed_base_dev(_p(base), _vp(d_scalars), C.c_size_t(n), _vp(d_out), _vp(stream)), "zkg_g2_fixed_base_dev")
+
+
+def timing_reset():
+    lib().zkg_timing_reset()
+
+
+def timing_dominant_ms():
+    n = C.c_int(0)
+    ms = lib().zkg_timing_dominant_ms(C.byref(n))
+    return float(ms), n.value
+
+
+# ---- Groth16 (r1cs_gg_ppzksnark_prover, snark.cpp:126) ---------------------------------------------
+def make_r1cs(n, l, A, B, Cm, keep):
+    """A, B, Cm = (rowptr uint32[C+1], col uint32[nnz], val uint64[nnz,4] Montgomery Fr); `keep` pins the arrays."""
+    cs = R1CS()
+    cs.num_variables, cs.num_inputs, cs.num_constraints = n, l, len(A[0]) - 1
+    for name, (rp, col, val) in zip("abc", (A, B, Cm)):
+        rp = np.ascontiguousarray(rp, np.uint32); col = np.ascontiguousarray(col, np.uint32); val = _u64(val)
+        keep += [rp, col, val]
+        setattr(cs, f"{name}_rowptr", rp.ctypes.data); setattr(cs, f"{name}_col", col.ctypes.data); setattr(cs, f"{name}_val", val.ctypes.data)
+    return cs
+
+
+def make_pk(cs, arrays, log_m, keep):
+    pk = PK(); pk.cs = cs; pk.log_m = log_m
+    for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query"):
+        a = _u64(arrays[k]); keep.append(a)
+        setattr(pk, k, a.ctypes.data)
+    return pk
+
+
+class Crs:
+    """Device-resident proving key (zkg_crs_upload): parsed once, reused for every proof."""
+
+    def __init__(self, pk):
+        self._h = lib().zkg_crs_upload(C.byref(pk))
+        if not self._h:
+            raise ZkgError("zkg_crs_upload failed: " + lib().zkg_last_error().decode())
+        self.m = 1 << pk.log_m
+
+    def prove(self, witness, r, s, check_satisfied=True):
+        """-> (rc, proof bytes); rc == 1 reproduces libsnark_prove's 'system not satisfied' return."""
+        out = np.zeros(256, np.uint8); ln = C.c_size_t(0)
+        rc = lib().zkg_groth16_prove(C.c_void_p(self._h), _p(_u64(witness)), _p(_u64(r)), _p(_u64(s)), int(check_satisfied), _p(out), C.byref(ln))
+        if rc not in (0, 1):
+            _check(rc, "zkg_groth16_prove")
+        return rc, bytes(out[:ln.value])
+
+    def qap_witness_h(self, witness):
+        out = np.zeros((self.m + 1, 4), np.uint64)
+        _check(lib().zkg_qap_witness_h(C.c_void_p(self._h), _p(_u64(witness)), _p(out)), "zkg_qap_witness_h")
+        return out
+
+    def stage_ms(self):
+        ms = (C.c_float * 8)()
+        _check(lib().zkg_prove_stage_ms(C.c_void_p(self._h), ms), "zkg_prove_stage_ms")
+        return list(ms)
+
+    def free(self):
+        if self._h:
+            lib().zkg_crs_free(C.c_void_p(self._h)); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

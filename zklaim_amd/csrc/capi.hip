@@ -1,0 +1,196 @@
+// capi.hip — the C ABI of include/zkg.h over the HIP kernels (host code only).
+//
+// This is the thin shim the reference's C/C++ front-end binds instead of libsnark: the entry
+// points sit directly below r1cs_gg_ppzksnark_prover (/root/reference/zklaim/snark.cpp:126).
+// There is no CPU fallback: every entry point fails with ZKG_ERROR when no HIP device is usable.
+#include "common.hpp"
+#include "../../include/zkg.h"
+#include <cstring>
+#include <mutex>
+
+namespace zk {
+
+static thread_local std::string t_error;
+static std::string g_error;
+static std::mutex g_err_mu;
+void set_error(const std::string &msg) { t_error = msg; std::lock_guard<std::mutex> lk(g_err_mu); g_error = msg; }
+bool hip_ok(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e) + " at " + file + ":" + std::to_string(line));
+    return false;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (!hip_ok(hipMalloc(&p, want), "hipMalloc", __FILE__, __LINE__)) { p = nullptr; return 1; }
+    cap = want;
+    return 0;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+KernelTimer g_dominant_timer;
+void KernelTimer::begin(hipStream_t s) {
+    if (!enabled) return;
+    if (used == pairs.size()) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; } pairs.push_back({a, b}); }
+    (void)hipEventRecord(pairs[used].first, s);
+}
+void KernelTimer::end(hipStream_t s) { if (!enabled || used >= pairs.size()) return; (void)hipEventRecord(pairs[used].second, s); ++used; }
+float KernelTimer::drain(int *launches) {
+    float total = 0; int n = 0;
+    for (size_t i = 0; i < used; ++i) {
+        float ms = 0;
+        if (hipEventSynchronize(pairs[i].second) == hipSuccess && hipEventElapsedTime(&ms, pairs[i].first, pairs[i].second) == hipSuccess) { total += ms; ++n; }
+    }
+    if (launches) *launches = n;
+    return n ? total / n : 0.f;
+}
+void KernelTimer::reset() { used = 0; }
+
+// ---- ABI point encodings -----------------------------------------------------------------------
+static void put(uint64_t *out, const Fq &a) { memcpy(out, a.v, 32); }
+static Fq get(const uint64_t *in) { Fq r; memcpy(r.v, in, 32); return r; }
+void store_norm(uint64_t *out, const G1 &p) {
+    G1Affine a = p.to_affine();
+    if (p.is_inf()) { put(out, Fq::zero()); put(out + 4, Fq::one()); put(out + 8, Fq::zero()); }
+    else { put(out, a.x); put(out + 4, a.y); put(out + 8, Fq::one()); }
+}
+void store_norm(uint64_t *out, const G2 &p) {
+    G2Affine a = p.to_affine();
+    if (p.is_inf()) { put(out, Fq::zero()); put(out + 4, Fq::zero()); put(out + 8, Fq::one()); put(out + 12, Fq::zero()); put(out + 16, Fq::zero()); put(out + 20, Fq::zero()); }
+    else { put(out, a.x.c0); put(out + 4, a.x.c1); put(out + 8, a.y.c0); put(out + 12, a.y.c1); put(out + 16, Fq::one()); put(out + 20, Fq::zero()); }
+}
+G1 load_norm_g1(const uint64_t *in) {
+    Fq z = get(in + 8);
+    if (z.is_zero()) return G1::inf();
+    return {get(in), get(in + 4), Fq::one(), Fq::one()};           // normalised: Z == 1
+}
+G2 load_norm_g2(const uint64_t *in) {
+    Fq2 z = {get(in + 16), get(in + 20)};
+    if (z.is_zero()) return G2::inf();
+    return {{get(in), get(in + 4)}, {get(in + 8), get(in + 12)}, Fq2::one(), Fq2::one()};
+}
+
+static std::mutex g_init_mu;
+static int g_device = -1;
+static void kernels_configure() { (void)ntt_configure(); (void)msm_configure(); }
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zkg_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("zkg_init: no HIP device visible (this library has no CPU fallback)"); return ZKG_ERROR; }
+    if (device < 0 || device >= count) { set_error("zkg_init: bad device index"); return ZKG_ERROR; }
+    ZK_HIP(hipSetDevice(device));
+    g_device = device;
+    kernels_configure();
+    return ZKG_OK;
+}
+void zkg_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_device < 0) return;
+    (void)hipDeviceSynchronize();
+    ntt_release_all();
+    msm_release_all();
+    g_device = -1;
+}
+const char *zkg_last_error(void) { std::lock_guard<std::mutex> lk(g_err_mu); static std::string copy; copy = g_error; return copy.c_str(); }
+
+int zkg_device_info(char *name, size_t name_len, int *compute_units) {
+    if (g_device < 0) { set_error("zkg_init not called"); return ZKG_ERROR; }
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, g_device));
+    if (name && name_len) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return ZKG_OK;
+}
+
+#define REQUIRE_INIT() do { if (g_device < 0) { set_error("zkg_init not called"); return ZKG_ERROR; } } while (0)
+
+int zkg_ntt_dev(void *d_a, unsigned logN, int inverse, int coset, void *stream) {
+    REQUIRE_INIT();
+    if (logN > 28) { set_error("zkg_ntt: logN exceeds the 2-adicity (28) of Fr"); return ZKG_ERROR; }
+    hipStream_t s = (hipStream_t)stream;
+    NttDomain *d = ntt_domain(logN, s);
+    if (!d) return ZKG_ERROR;
+    return ntt_run(d, (Fr *)d_a, inverse, coset, s);
+}
+int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset) {
+    REQUIRE_INIT();
+    if (!a || logN > 28) { set_error("zkg_ntt: bad argument"); return ZKG_ERROR; }
+    size_t bytes = ((size_t)1 << logN) * 32;
+    DevBuf buf;
+    if (buf.reserve(bytes)) return ZKG_ERROR;
+    int rc = ZKG_ERROR;
+    if (hip_ok(hipMemcpy(buf.p, a, bytes, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+        zkg_ntt_dev(buf.p, logN, inverse, coset, nullptr) == ZKG_OK &&
+        hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) &&
+        hip_ok(hipMemcpy(a, buf.p, bytes, hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) rc = ZKG_OK;
+    buf.release();
+    return rc;
+}
+
+int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
+    REQUIRE_INIT();
+    G1 r;
+    if (msm_g1((const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, true, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    store_norm(out_jac, r);
+    return ZKG_OK;
+}
+int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[24], void *stream) {
+    REQUIRE_INIT();
+    G2 r;
+    if (msm_g2((const G2Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, true, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    store_norm(out_jac, r);
+    return ZKG_OK;
+}
+static int msm_host(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t *out, int g2) {
+    REQUIRE_INIT();
+    if (n && (!bases || !scalars)) { set_error("zkg_msm: null input"); return ZKG_ERROR; }
+    size_t bb = n * (g2 ? 128 : 64), sb = n * 32;
+    DevBuf db, ds;
+    if (db.reserve(bb + 16) || ds.reserve(sb + 16)) return ZKG_ERROR;
+    int rc = ZKG_ERROR;
+    if ((!n || (hip_ok(hipMemcpy(db.p, bases, bb, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+                hip_ok(hipMemcpy(ds.p, scalars, sb, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__))))
+        rc = g2 ? zkg_msm_g2_dev(db.p, ds.p, n, 0, out, nullptr) : zkg_msm_g1_dev(db.p, ds.p, n, 0, out, nullptr);
+    db.release(); ds.release();
+    return rc;
+}
+int zkg_msm_g1(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[12]) { return msm_host(bases, scalars, n, out_jac, 0); }
+int zkg_msm_g2(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[24]) { return msm_host(bases, scalars, n, out_jac, 1); }
+
+int zkg_g1_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[12]) {
+    G1 acc = G1::inf();
+    for (size_t i = 0; i < count; ++i) acc.add(load_norm_g1(points_jac + 12 * i));
+    store_norm(out_jac, acc);
+    return ZKG_OK;
+}
+int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]) {
+    G2 acc = G2::inf();
+    for (size_t i = 0; i < count; ++i) acc.add(load_norm_g2(points_jac + 24 * i));
+    store_norm(out_jac, acc);
+    return ZKG_OK;
+}
+
+int zkg_g1_fixed_base_dev(const uint64_t base[8], const void *d_scalars, size_t n, void *d_out_affine, void *stream) {
+    REQUIRE_INIT();
+    G1Affine b; memcpy(&b, base, 64);
+    return fixed_base_g1(b, (const uint32_t *)d_scalars, n, (G1Affine *)d_out_affine, (hipStream_t)stream);
+}
+int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t n, void *d_out_affine, void *stream) {
+    REQUIRE_INIT();
+    G2Affine b; memcpy(&b, base, 128);
+    return fixed_base_g2(b, (const uint32_t *)d_scalars, n, (G2Affine *)d_out_affine, (hipStream_t)stream);
+}
+
+void zkg_timing_reset(void) { g_dominant_timer.reset(); }
+float zkg_timing_dominant_ms(int *launches) { return g_dominant_timer.drain(launches); }
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// common.hpp — host-side plumbing shared by the HIP translation units of libzkg.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "curve.cuh"
+
+namespace zk {
+
+void set_error(const std::string &msg);
+bool hip_ok(hipError_t e, const char *what, const char *file, int line);
+#define ZK_HIP(expr) do { if (!::zk::hip_ok((expr), #expr, __FILE__, __LINE__)) return ZKG_ERROR; } while (0)
+#define ZK_HIP_V(expr) do { if (!::zk::hip_ok((expr), #expr, __FILE__, __LINE__)) return; } while (0)
+
+// grow-only device buffer (workspaces are allocated outside the timed path and reused)
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// HIP-event timing of the dominant kernel (bench.py's roofline.achieved), on the launch stream
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs; size_t used = 0; bool enabled = true;
+    void begin(hipStream_t s); void end(hipStream_t s);
+    float drain(int *launches);       // average ms since last reset (synchronises the events)
+    void reset();
+};
+extern KernelTimer g_dominant_timer;
+
+// ---------------- NTT (ntt.hip) ----------------
+struct NttDomain {
+    unsigned logn = 0;
+    DevBuf tw_fwd, tw_inv;        // omega^i, omega^-i, i < N/2
+    DevBuf coset_pre;             // g^i               (cosetFFT pre-multiplication)
+    DevBuf icoset_post;           // g^-i / N          (icosetFFT post-multiplication, 1/N folded in)
+    DevBuf scratch;               // N elements
+    Fr n_inv;                     // 1/N
+    int init(unsigned logn, hipStream_t s);
+    void release();
+};
+NttDomain *ntt_domain(unsigned logn, hipStream_t s);     // cached per size
+// mode: inverse / coset as in zkg_ntt.  extra_post (device, N Fr, optional) replaces the default
+// post table: the prover fuses iFFT's 1/N with the following cosetFFT's g^i through it.
+int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s);
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s);
+int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s);   // out[i] = scale * base^i
+void ntt_release_all();
+int ntt_configure();
+
+// ---------------- MSM (msm.hip) ----------------
+struct MsmPlan;                                            // per-(curve,N) workspace + sorted digit lists
+template <class F> struct MsmResult { XYZZ<F> value; };
+// scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  filter01: route scalars equal to
+// 0 / 1 around the bucket method (libff multi_exp_with_mixed_addition).
+int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, bool filter01, G1 *out, hipStream_t s);
+int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, bool filter01, G2 *out, hipStream_t s);
+// one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
+int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
+               bool scalars_mont, bool filter01, G1 *out_g1, G2 *out_g2, hipStream_t s);
+int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s);
+int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s);
+void msm_release_all();
+int msm_configure();
+
+// ---------------- ABI encodings (capi.cpp) ----------------
+void store_norm(uint64_t *out, const G1 &p);   // normalised jac, 12 limbs
+void store_norm(uint64_t *out, const G2 &p);   // 24 limbs
+G1 load_norm_g1(const uint64_t *in);
+G2 load_norm_g2(const uint64_t *in);
+
+}  // namespace zk

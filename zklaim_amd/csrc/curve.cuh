@@ -1,0 +1,103 @@
+// curve.cuh — alt_bn128 G1 (over Fq) and G2 (over Fq2) group law, y^2 = x^3 + b, a = 0.
+//
+// Replaces libff's alt_bn128_G1 / alt_bn128_G2 add, mixed_add, dbl, to_affine_coordinates
+// (reached from the multi_exp calls inside r1cs_gg_ppzksnark_prover, /root/reference/zklaim/snark.cpp:126).
+//
+// libff keeps Jacobian (X,Y,Z).  The accumulators here use extended Jacobian "XYZZ"
+// coordinates (X, Y, ZZ, ZZZ with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): the mixed addition that
+// dominates the MSM costs 8M+2S instead of 7M+4S and needs no field doubling chain.  Group
+// elements are exact, so any coordinate system gives the same affine result; outputs cross the
+// ABI only in normalised form (include/zkg.h).  Infinity: ZZ == 0 (XYZZ), x == y == 0 (affine).
+#pragma once
+#include "fp.cuh"
+
+// Out-of-line group operations keep the code size (and hipcc time) in check: a G2 addition is
+// ~40 base-field multiplications of ~600 instructions each.  Only madd(), the hot operation of the
+// bucket accumulation, stays inline; its rare doubling path does not.
+#define ZK_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+
+namespace zk {
+
+template <class F> struct Affine {
+    F x, y;
+    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    static ZK_HD Affine inf() { return {F::zero(), F::zero()}; }
+    ZK_HD Affine neg() const { return {x, y.neg()}; }
+};
+
+template <class F> struct XYZZ {
+    F x, y, zz, zzz;
+    static ZK_HD XYZZ inf() { return {F::zero(), F::one(), F::zero(), F::zero()}; }
+    static ZK_HD XYZZ from_affine(const Affine<F> &a) { return a.is_inf() ? inf() : XYZZ{a.x, a.y, F::one(), F::one()}; }
+    ZK_HD bool is_inf() const { return zz.is_zero(); }
+    ZK_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
+
+    // dbl-2008-s-1
+    ZK_HD_NOINLINE XYZZ dbl() const {
+        if (is_inf()) return *this;
+        F U = y.dbl(), V = U.sqr(), W = U * V, S = x * V;
+        F xx = x.sqr(), M = xx.dbl() + xx;
+        F X3 = M.sqr() - S.dbl();
+        F Y3 = M * (S - X3) - W * y;
+        return {X3, Y3, V * zz, W * zzz};
+    }
+    // doubling of an affine point (mdbl-2008-s-1)
+    static ZK_HD_NOINLINE XYZZ dbl_affine(const Affine<F> &a) {
+        F U = a.y.dbl(), V = U.sqr(), W = U * V, S = a.x * V;
+        F xx = a.x.sqr(), M = xx.dbl() + xx;
+        F X3 = M.sqr() - S.dbl();
+        F Y3 = M * (S - X3) - W * a.y;
+        return {X3, Y3, V, W};
+    }
+    // madd-2008-s, with the exceptional cases (this == inf, b == inf, b == +-this) handled
+    ZK_HD void madd(const Affine<F> &b) {
+        if (b.is_inf()) return;
+        if (is_inf()) { *this = {b.x, b.y, F::one(), F::one()}; return; }
+        F U2 = b.x * zz, S2 = b.y * zzz;
+        F P = U2 - x, R = S2 - y;
+        if (P.is_zero()) {
+            if (R.is_zero()) *this = dbl_affine(b); else *this = inf();
+            return;
+        }
+        F PP = P.sqr(), PPP = P * PP, Q = x * PP;
+        F X3 = R.sqr() - PPP - Q.dbl();
+        F Y3 = R * (Q - X3) - y * PPP;
+        x = X3; y = Y3; zz = zz * PP; zzz = zzz * PPP;
+    }
+    // add-2008-s, exceptional cases handled
+    ZK_HD_NOINLINE void add(const XYZZ &b) {
+        if (b.is_inf()) return;
+        if (is_inf()) { *this = b; return; }
+        F U1 = x * b.zz, U2 = b.x * zz, S1 = y * b.zzz, S2 = b.y * zzz;
+        F P = U2 - U1, R = S2 - S1;
+        if (P.is_zero()) {
+            if (R.is_zero()) *this = dbl(); else *this = inf();
+            return;
+        }
+        F PP = P.sqr(), PPP = P * PP, Q = U1 * PP;
+        F X3 = R.sqr() - PPP - Q.dbl();
+        F Y3 = R * (Q - X3) - S1 * PPP;
+        x = X3; y = Y3; zz = zz * b.zz * PP; zzz = zzz * b.zzz * PPP;
+    }
+    ZK_HD_NOINLINE Affine<F> to_affine() const {
+        if (is_inf()) return Affine<F>::inf();
+        F zi = zzz.inverse();              // 1/ZZZ ;  1/ZZ = ZZZ^-2 * ZZ^2 ... use x = X * (zi*ZZ)^2
+        F t = zi * zz;                     // = ZZ/ZZZ = 1/Z
+        F zi2 = t.sqr();                   // 1/ZZ
+        return {x * zi2, y * zi};
+    }
+    // k * this for a canonical little-endian u32 scalar (host: proof assembly; device: fixed-base tables)
+    ZK_HD_NOINLINE XYZZ mul(const uint32_t *k, int nlimbs) const {
+        XYZZ r = inf();
+        for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+            r = r.dbl();
+            if ((k[i >> 5] >> (i & 31)) & 1u) r.add(*this);
+        }
+        return r;
+    }
+};
+
+typedef Affine<Fq> G1Affine;  typedef XYZZ<Fq> G1;
+typedef Affine<Fq2> G2Affine; typedef XYZZ<Fq2> G2;
+
+}  // namespace zk
