@@ -87,16 +87,11 @@ def main():
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
-    gather = [torch.empty(12, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+    from zklaim_amd import dist as zdist
 
     def step():
         part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)       # normalised partial (host)
-        if world == 1:
-            return part
-        mine = torch.from_numpy(part.view(np.int64)).cuda()
-        dist.all_gather(gather, mine)
-        pts = torch.stack(gather).cpu().numpy().view(np.uint64)
-        return zkg.g1_sum(pts)
+        return zdist.combine_partials_g1(part, device="cuda") if world > 1 else part
 
     def fence():
         if world > 1:

@@ -1,11 +1,241 @@
-// prover.hip — placeholder (Groth16 pipeline lands next)
+// prover.hip — Groth16 prover pipeline on a device-resident proving key.
+//
+// Replaces libsnark's r1cs_gg_ppzksnark_prover<ppT>(pk, primary_input, auxiliary_input), the call at
+// /root/reference/zklaim/snark.cpp:126, including r1cs_to_qap_witness_map (3 sparse mat-vecs, 3 iFFT,
+// 3 cosetFFT, pointwise H = (A.B - C)/Z on the coset, 1 icosetFFT) and the four multi-exponentiations
+// (A query; B query in G2 and G1; H query; L query), and the proof serialisation operator<< reached from
+// zklaim/libsnark_wrapper.cpp:170-181.
+//
+// What differs from the reference by design: the pk is parsed and uploaded ONCE (zkg_crs_upload) instead
+// of on every call (libsnark_wrapper.cpp:230 + the by-value copy at snark.cpp:107-109); iFFT's 1/m and
+// the following cosetFFT's g^i are one fused table multiplication; A, B_g1 and B_g2 share one digit sort
+// because they share the scalar vector [1 | w]; the prover randomness (r, s) is an explicit input.
 #include "common.hpp"
 #include "../../include/zkg.h"
-using namespace zk;
-extern "C" {
-zkg_crs *zkg_crs_upload(const zkg_pk *) { set_error("not implemented"); return nullptr; }
-void zkg_crs_free(zkg_crs *) {}
-int zkg_groth16_prove(const zkg_crs *, const uint64_t *, const uint64_t *, const uint64_t *, int, uint8_t *, size_t *) { return ZKG_ERROR; }
-int zkg_qap_witness_h(const zkg_crs *, const uint64_t *, uint64_t *) { return ZKG_ERROR; }
-int zkg_prove_stage_ms(const zkg_crs *, float *) { return ZKG_ERROR; }
+#include <cstring>
+#include <mutex>
+
+namespace zk {
+
+struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
+
+}  // namespace zk
+
+struct zkg_crs {
+    uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0;
+    zk::DevCsr A, B, Cm;
+    zk::DevBuf A_query, B_g1, B_g2, H_query, L_query;
+    zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
+    zk::NttDomain *dom = nullptr;
+    zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
+    zk::DevBuf z, aA, aB, aC, flag;             // [1 | w] and the three evaluation vectors
+    zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
+    float stage_ms[8] = {0};
+    hipEvent_t ev[9]; bool ev_ok = false;
+    std::mutex mu;
+};
+
+namespace zk {
+
+// one lane per constraint row: <A_i,z>, <B_i,z>, <C_i,z>; rows C..C+l of aA carry the input-consistency
+// terms (r1cs_to_qap_witness_map); flag |= 1 when a row violates <A,z><B,z> = <C,z> (snark.cpp:121-124)
+__global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
+                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
+                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
+                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, uint32_t *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
+    if (i < C) {
+        for (uint32_t k = a_rp[i]; k < a_rp[i + 1]; ++k) a += a_val[k] * z[a_col[k]];
+        for (uint32_t k = b_rp[i]; k < b_rp[i + 1]; ++k) b += b_val[k] * z[b_col[k]];
+        for (uint32_t k = c_rp[i]; k < c_rp[i + 1]; ++k) c += c_val[k] * z[c_col[k]];
+        if (a * b != c) atomicOr(flag, 1u);
+    } else if (i <= (size_t)C + l) {
+        a = z[i - C];
+    }
+    aA[i] = a; aB[i] = b; aC[i] = c;
 }
+
+__global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one(); }
+
+// H_tmp = (aA . aB - aC) * Zinv  (divide_by_Z_on_coset fused with the pointwise product)
+__global__ __launch_bounds__(256) void k_pointwise_h(Fr *aA, const Fr *aB, const Fr *aC, size_t m, Fr zinv) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    aA[i] = (aA[i] * aB[i] - aC[i]) * zinv;
+}
+
+static int upload(DevBuf &d, const void *src, size_t bytes) {
+    if (d.reserve(bytes ? bytes : 16)) return ZKG_ERROR;
+    if (bytes && !hip_ok(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__)) return ZKG_ERROR;
+    return ZKG_OK;
+}
+static int upload_csr(DevCsr &d, const uint32_t *rp, const uint32_t *col, const uint64_t *val, uint32_t rows) {
+    if (!rp) { set_error("crs: null CSR"); return ZKG_ERROR; }
+    d.nnz = rp[rows];
+    if (upload(d.rowptr, rp, (size_t)(rows + 1) * 4) || upload(d.col, col, d.nnz * 4) || upload(d.val, val, d.nnz * 32)) return ZKG_ERROR;
+    return ZKG_OK;
+}
+
+// ---- host-side proof assembly ---------------------------------------------------------------------
+static void canonical_limbs(const Fr &x, uint32_t out[8]) { Fr c = x.from_mont(); for (int i = 0; i < 8; ++i) out[i] = c.v[i]; }
+static bool canonical_lsb(const Fq &y) { return y.from_mont().v[0] & 1u; }
+static size_t ser_g1(uint8_t *out, const G1 &p) {        // libff operator<<(alt_bn128_G1): binary, Montgomery, compressed
+    G1Affine a = p.to_affine(); bool inf = p.is_inf();
+    Fq x = inf ? Fq::zero() : a.x, y = inf ? Fq::one() : a.y;
+    out[0] = inf ? '1' : '0'; memcpy(out + 1, x.v, 32); out[33] = canonical_lsb(y) ? '1' : '0';
+    return 34;
+}
+static size_t ser_g2(uint8_t *out, const G2 &p) {
+    G2Affine a = p.to_affine(); bool inf = p.is_inf();
+    Fq2 x = inf ? Fq2::zero() : a.x, y = inf ? Fq2::one() : a.y;
+    out[0] = inf ? '1' : '0'; memcpy(out + 1, x.c0.v, 32); memcpy(out + 33, x.c1.v, 32); out[65] = canonical_lsb(y.c0) ? '1' : '0';
+    return 66;
+}
+
+static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint32_t *flag_out, hipStream_t s) {
+    const size_t m = crs->m;
+    Fr *z = crs->z.as<Fr>(), *aA = crs->aA.as<Fr>(), *aB = crs->aB.as<Fr>(), *aC = crs->aC.as<Fr>();
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
+    if (crs->n) ZK_HIP(hipMemcpyAsync(z + 1, witness, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
+    ZK_HIP(hipMemsetAsync(crs->flag.p, 0, 4, s));
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[0], s);
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
+                       crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
+                       crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
+                       crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(),
+                       z, crs->C, crs->l, m, aA, aB, aC, crs->flag.as<uint32_t>());
+    if (want_flag) ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
+    // iFFT then cosetFFT, for each of aA, aB, aC: inverse transform with post table g^i/m, then a plain forward transform
+    const Fr *fused = crs->coset_over_m.as<Fr>();
+    for (Fr *v : {aA, aB, aC}) {
+        if (ntt_run_ex(crs->dom, v, true, nullptr, fused, nullptr, s)) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, v, false, nullptr, nullptr, nullptr, s)) return ZKG_ERROR;
+    }
+    hipLaunchKernelGGL(k_pointwise_h, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
+    if (ntt_run(crs->dom, aA, 1, 1, s)) return ZKG_ERROR;                    // icosetFFT -> coefficients_for_H[0..m)
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
+    if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
+    return ZKG_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
+    if (!pk) { set_error("zkg_crs_upload: null pk"); return nullptr; }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("zkg_crs_upload: no HIP device (call zkg_init)"); return nullptr; }
+    const zkg_r1cs &cs = pk->cs;
+    if (pk->log_m > 28 || ((size_t)cs.num_constraints + cs.num_inputs + 1) > ((size_t)1 << pk->log_m) || cs.num_inputs > cs.num_variables) {
+        set_error("zkg_crs_upload: inconsistent sizes"); return nullptr;
+    }
+    zkg_crs *crs = new zkg_crs();
+    crs->n = cs.num_variables; crs->l = cs.num_inputs; crs->C = cs.num_constraints; crs->log_m = pk->log_m; crs->m = (size_t)1 << pk->log_m;
+    const size_t n = crs->n, l = crs->l, m = crs->m;
+    bool ok = upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
+              upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
+    ok = ok && upload(crs->A_query, pk->A_query, (n + 1) * 64) == 0 && upload(crs->B_g1, pk->B_g1, (n + 1) * 64) == 0 &&
+         upload(crs->B_g2, pk->B_g2, (n + 1) * 128) == 0 && upload(crs->H_query, pk->H_query, (m - 1) * 64) == 0 &&
+         upload(crs->L_query, pk->L_query, (n - l) * 64) == 0;
+    if (ok) {
+        memcpy(&crs->alpha_g1, pk->alpha_g1, 64); memcpy(&crs->beta_g1, pk->beta_g1, 64); memcpy(&crs->delta_g1, pk->delta_g1, 64);
+        memcpy(&crs->beta_g2, pk->beta_g2, 128); memcpy(&crs->delta_g2, pk->delta_g2, 128);
+        crs->dom = ntt_domain(pk->log_m, nullptr);
+        ok = crs->dom != nullptr;
+    }
+    if (ok) {
+        Fr g = Fr::from_u64(5);
+        crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
+        ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
+             crs->z.reserve((n + 1) * 32) == 0 && crs->aA.reserve(m * 32) == 0 && crs->aB.reserve(m * 32) == 0 && crs->aC.reserve(m * 32) == 0 &&
+             crs->flag.reserve(4) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+    }
+    if (ok) {
+        crs->ev_ok = true;
+        for (auto &e : crs->ev) if (hipEventCreate(&e) != hipSuccess) crs->ev_ok = false;
+    }
+    if (!ok) { zkg_crs_free(crs); return nullptr; }
+    return crs;
+}
+
+void zkg_crs_free(zkg_crs *crs) {
+    if (!crs) return;
+    for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
+                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag})
+        b->release();
+    if (crs->ev_ok) for (auto &e : crs->ev) (void)hipEventDestroy(e);
+    delete crs;
+}
+
+int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
+    zkg_crs *crs = const_cast<zkg_crs *>(crs_);
+    if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }
+    std::lock_guard<std::mutex> lk(crs->mu);
+    uint32_t flag = 0;
+    if (compute_h(crs, witness, false, &flag, nullptr)) return ZKG_ERROR;
+    ZK_HIP(hipMemcpy(h_out, crs->aA.p, crs->m * 32, hipMemcpyDeviceToHost));
+    memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
+    return ZKG_OK;
+}
+
+int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64_t r_[4], const uint64_t s_[4], int check_satisfied,
+                      uint8_t *proof_out, size_t *proof_len) {
+    zkg_crs *crs = const_cast<zkg_crs *>(crs_);
+    if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !witness)) { set_error("zkg_groth16_prove: bad argument"); return ZKG_ERROR; }
+    std::lock_guard<std::mutex> lk(crs->mu);
+    hipStream_t s = nullptr;
+    const size_t n = crs->n, l = crs->l, m = crs->m;
+    uint32_t flag = 0;
+    if (compute_h(crs, witness, check_satisfied != 0, &flag, s)) return ZKG_ERROR;
+    if (check_satisfied) {
+        ZK_HIP(hipStreamSynchronize(s));
+        if (flag) { set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED; }
+    }
+    // ---- multi-exponentiations.  Scalars are Montgomery Fr on device (converted on the fly).
+    const uint32_t *z = crs->z.as<uint32_t>();
+    const G1Affine *g1sets[2] = {crs->A_query.as<G1Affine>(), crs->B_g1.as<G1Affine>()};
+    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
+    if (msm_shared(g1sets, 2, crs->B_g2.as<G2Affine>(), z, n + 1, true, true, AB, &Bt2, s)) return ZKG_ERROR;
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[3], s);
+    if (msm_g1(crs->H_query.as<G1Affine>(), crs->aA.as<uint32_t>(), m - 1, true, true, &Ht, s)) return ZKG_ERROR;
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[4], s);
+    if (msm_g1(crs->L_query.as<G1Affine>(), z + 8 * (l + 1), n - l, true, true, &Lt, s)) return ZKG_ERROR;
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[5], s);
+    // ---- assembly (host; a handful of scalar multiplications)
+    Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
+    uint32_t rc[8], sc[8], rsc[8];
+    canonical_limbs(r, rc); canonical_limbs(sv, sc); canonical_limbs(r * sv, rsc);
+    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
+    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
+    G1 gA = alpha; gA.add(AB[0]); gA.add(delta1.mul(rc, 8));                // A = alpha + sum a_i A_i(t) + r delta
+    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(delta1.mul(sc, 8));             // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
+    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(delta2.mul(sc, 8));               //                                        (G2)
+    G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(delta1.mul(rsc, 8).neg());
+    size_t off = 0;
+    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
+    *proof_len = off;
+    if (crs->ev_ok) {
+        (void)hipEventRecord(crs->ev[6], s);
+        if (hipEventSynchronize(crs->ev[6]) == hipSuccess) {
+            float t;
+            auto el = [&](int a, int b) { return hipEventElapsedTime(&t, crs->ev[a], crs->ev[b]) == hipSuccess ? t : -1.f; };
+            crs->stage_ms[0] = el(0, 1); crs->stage_ms[1] = el(1, 2); crs->stage_ms[2] = el(2, 3); crs->stage_ms[3] = 0; crs->stage_ms[4] = 0;
+            crs->stage_ms[5] = el(3, 4); crs->stage_ms[6] = el(4, 5); crs->stage_ms[7] = el(0, 6);
+        }
+    }
+    return ZKG_OK;
+}
+
+int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
+    if (!crs || !ms) return ZKG_ERROR;
+    for (int i = 0; i < 8; ++i) ms[i] = crs->stage_ms[i];
+    return ZKG_OK;
+}
+
+}  // extern "C"
