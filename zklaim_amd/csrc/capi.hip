@@ -139,14 +139,14 @@ int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset) {
 int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
     REQUIRE_INIT();
     G1 r;
-    if (msm_g1((const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, true, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    if (msm_g1((const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, (hipStream_t)stream)) return ZKG_ERROR;
     store_norm(out_jac, r);
     return ZKG_OK;
 }
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[24], void *stream) {
     REQUIRE_INIT();
     G2 r;
-    if (msm_g2((const G2Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, true, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    if (msm_g2((const G2Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, (hipStream_t)stream)) return ZKG_ERROR;
     store_norm(out_jac, r);
     return ZKG_OK;
 }

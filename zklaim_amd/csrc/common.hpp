@@ -54,13 +54,13 @@ int ntt_configure();
 // ---------------- MSM (msm.hip) ----------------
 struct MsmPlan;                                            // per-(curve,N) workspace + sorted digit lists
 template <class F> struct MsmResult { XYZZ<F> value; };
-// scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  filter01: route scalars equal to
-// 0 / 1 around the bucket method (libff multi_exp_with_mixed_addition).
-int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, bool filter01, G1 *out, hipStream_t s);
-int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, bool filter01, G2 *out, hipStream_t s);
+// scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  Zero scalars are dropped and ones land in
+// one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
+int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s);
+int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G2 *out, hipStream_t s);
 // one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, bool filter01, G1 *out_g1, G2 *out_g2, hipStream_t s);
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s);
 int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s);
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s);
 void msm_release_all();

@@ -12,6 +12,8 @@
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include "mont_asm.inc"
 
 #define ZK_HD __host__ __device__ __forceinline__
 #define ZK_D __device__ __forceinline__
@@ -74,26 +76,26 @@ struct alignas(16) Fp {
 
     // Montgomery product a*b*R^-1 mod p.
     friend ZK_HD Fp operator*(const Fp &a, const Fp &b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        // CIOS over 32-bit limbs, two interleaved carry chains (product and reduction), no extra
-        // carry word because the top limb of p is < 2^31 (p < 2^254).  Each step is one
-        // v_mad_u64_u32 plus a 64-bit add.
-        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint64_t x = (uint64_t)a.v[0] * b.v[i] + t[0];
-            uint32_t m = (uint32_t)x * PR::INV32;
-            uint64_t y = (uint64_t)m * PR::P[0] + (uint32_t)x;
-            uint32_t c = (uint32_t)(x >> 32), c2 = (uint32_t)(y >> 32);
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                x = (uint64_t)a.v[j] * b.v[i] + t[j] + c; c = (uint32_t)(x >> 32);
-                y = (uint64_t)m * PR::P[j] + (uint32_t)x + c2; c2 = (uint32_t)(y >> 32);
-                t[j - 1] = (uint32_t)y;
-            }
-            t[7] = c + c2;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+        // Hand-scheduled gfx950 stream (tools/gen_mont_asm.py): product scanning with a 96-bit column accumulator,
+        // one v_mad_u64_u32 + one v_addc_co_u32 per partial product.  Result in [0, 2p).
+        uint32_t t[8]; uint64_t c0, c1, c2;
+        if constexpr (std::is_same<PR, FqParams>::value) {
+            asm(ZK_MONT_MUL_ASM_FQ
+                : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_MONT_MUL_CLOBBERS);
+        } else {
+            asm(ZK_MONT_MUL_ASM_FR
+                : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_MONT_MUL_CLOBBERS);
         }
         return reduce_once(t);
+#elif defined(__HIP_DEVICE_COMPILE__)
+        // portable C++ form of the same product (kept for A/B checks: -DZK_MONT_CXX): CIOS over 32-bit limbs
 #else
         typedef unsigned __int128 u128;
         uint64_t A[4], B[4], P4[4], t[4] = {0, 0, 0, 0};

@@ -4,21 +4,28 @@
 // kc_multi_exp_with_mixed_addition (the A/B/H/L query multi-exponentiations inside
 // r1cs_gg_ppzksnark_prover, /root/reference/zklaim/snark.cpp:126).
 //
-// libff walks the c-bit windows serially and mixed-adds every base into buckets[digit].  EC
-// addition is not atomic, so on the GPU the scatter is removed structurally:
-//   1. k_digits_count   signed c-bit digits of every scalar; per-(window,bucket) histogram
-//   2. k_scan           exclusive scan of the histogram -> bucket offsets
-//   3. k_scatter        point indices (sign in bit 0) grouped by (window,bucket)
-//   4. k_bucket_accum   one lane per bucket: sequential XYZZ mixed adds over its index list
-//                       (the dominant kernel: N*W mixed additions, bases gathered 64/128 B at a time)
-//      buckets longer than HEAVY_T entries (skewed scalars; the short top window) are cut into
-//      512-entry parts summed by one wavefront each (k_heavy_parts) and merged per bucket by an
-//      LDS tree (k_heavy_merge), so no lane ever walks a long list alone
-//   5. k_bucket_reduce  sum_b (b+1)*B_b per 2048-bucket chunk: per-lane running sums, then an
-//                       LDS suffix scan + tree reduction across the workgroup
-//   6. host             per-window chunk combine and the c-doublings Horner across windows
-// Scalars equal to 0 / 1 take libff's multi_exp_with_mixed_addition shortcut: zeros are
-// dropped, ones are summed by a strided + LDS tree reduction (zklaim witnesses are ~97 % bits).
+// libff walks the c-bit windows serially and mixed-adds every base into buckets[digit].  EC addition is
+// not atomic, so on the GPU the scatter is removed structurally — a counting sort by (window, bucket)
+// followed by conflict-free accumulation:
+//   1. k_digits        signed c-bit digits of every scalar, written window-major (4 B per digit)
+//   2. k_hist          one workgroup per (window, 64K-point slice): histogram of its digits in LDS
+//                      (2^(c-1) counters, up to 128 KiB of the CU's 160 KiB) -> hist[w][slice][bucket]
+//   3. k_colscan+scan  per-bucket totals and slice-relative offsets; exclusive scan -> bucket offsets
+//   4. k_place         same workgroup shape as 2: bucket cursors staged in LDS, point indices (sign in
+//                      bit 0) written to their final position.  No global atomics anywhere in the sort,
+//                      so skewed digits (bit witnesses, the short top window) cost nothing extra.
+//   5. k_order         bucket ids ordered by descending length, so the 64 lanes of a wavefront walk
+//                      lists of (nearly) equal length
+//   6. k_bucket_accum  one lane per bucket: sequential XYZZ mixed adds over its index list, next base
+//                      prefetched (the dominant kernel: N*W mixed additions, 64/128 B gathers).
+//                      Buckets longer than heavy_t leave this kernel: they are cut into 512-entry parts
+//                      summed by one wavefront each (k_heavy_parts) and merged per bucket by an LDS tree
+//                      (k_heavy_merge), so no lane ever walks a long list alone
+//   7. k_bucket_reduce sum_b (b+1)*B_b per 2048-bucket chunk: per-lane running sums, then an LDS suffix
+//                      scan + tree reduction across the workgroup
+//   8. host            per-window chunk combine and the c-doublings Horner across windows
+// Zero scalars are dropped in step 1 and scalars equal to one simply land in bucket (window 0, digit 1),
+// a "heavy" bucket: the effect of libff's multi_exp_with_mixed_addition prefilter without a special case.
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
@@ -30,24 +37,25 @@ static constexpr int SCALAR_BITS = 255;      // r < 2^254; one extra bit absorbs
 static constexpr int RED_THREADS = 256;
 static constexpr int RED_L = 8;              // buckets per lane in the running-sum step
 static constexpr int RED_CHUNK = RED_THREADS * RED_L;
-static constexpr int ONES_BLOCKS = 128;
-static constexpr uint32_t HEAVY_T = 256;     // buckets with more entries than this leave the lane-per-bucket kernel
+static constexpr int MAX_C = 16;             // LDS histogram: 2^(c-1) u32 counters <= 128 KiB
 static constexpr uint32_t HEAVY_S = 512;     // entries per heavy part (one wavefront sums one part)
+static constexpr uint32_t HEAVY_T_MAX = 1024;
 static constexpr int HEAVY_PART_BLOCKS = 1024, HEAVY_MERGE_BLOCKS = 256;
-
-struct HeavyItem { uint32_t start, end; };                    // a part: range of the sorted index list
-struct HeavyBucket { uint32_t gb, first_item, nparts; };
+static constexpr int SORT_THREADS = 1024;
+static constexpr int SCAN_ITEMS = 4;         // per thread in the block scan
 
 struct MsmGeom { uint32_t c, W, B; };        // window bits, windows, buckets per window (2^(c-1))
+struct HeavyItem { uint32_t start, end; };   // a part: range of the sorted index list
+struct HeavyBucket { uint32_t gb, first_item, nparts; };
 
 static MsmGeom pick_geom(size_t n) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg - 4; if (c < 4) c = 4; if (c > 20) c = 20;
+    int c = lg - 4; if (c < 4) c = 4; if (c > MAX_C) c = MAX_C;
     MsmGeom g; g.c = c; g.W = (SCALAR_BITS + c - 1) / c; g.B = 1u << (c - 1);
     return g;
 }
 
-// ---- scalar -> signed digits ---------------------------------------------------------------
+// ---- 1. scalar -> signed digits -----------------------------------------------------------------
 ZK_D uint32_t bits_at(const uint32_t v[8], uint32_t off, uint32_t c) {
     uint32_t limb = off >> 5, sh = off & 31;
     if (limb >= 8) return 0;
@@ -56,95 +64,162 @@ ZK_D uint32_t bits_at(const uint32_t v[8], uint32_t off, uint32_t c) {
     return (uint32_t)(x >> sh) & ((1u << c) - 1);
 }
 
-struct ScalarRead { uint32_t v[8]; int cls; };       // cls: 0 zero, 1 one, 2 general
-ZK_D ScalarRead read_scalar(const uint32_t *scalars, size_t i, int mont, int filter01) {
-    ScalarRead s; Fr f;
+// digit code: 0 = no contribution; otherwise ((bucket + 1) << 1) | negative, bucket = |d| - 1
+__global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, size_t n, int mont, MsmGeom g, uint32_t *digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr f;
     const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * i);
     uint4 a = p[0], b = p[1];
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
     if (mont) f = f.from_mont();
-    uint32_t hi = 0;
-    for (int k = 1; k < 8; ++k) hi |= f.v[k];
-    for (int k = 0; k < 8; ++k) s.v[k] = f.v[k];
-    s.cls = 2;
-    if (hi == 0 && f.v[0] == 0) s.cls = 0;                     // zero scalars never contribute
-    else if (filter01 && hi == 0 && f.v[0] == 1) s.cls = 1;
-    return s;
-}
-
-// visits every non-zero signed digit: fn(window, bucket (|d|-1), negative)
-template <class Fn> ZK_D void for_each_digit(const uint32_t v[8], MsmGeom g, Fn fn) {
     uint32_t carry = 0;
     for (uint32_t w = 0; w < g.W; ++w) {
-        uint32_t raw = bits_at(v, w * g.c, g.c) + carry;
-        if (raw > g.B) { uint32_t d = (1u << g.c) - raw; carry = 1; if (d) fn(w, d - 1, 1u); }
-        else { carry = 0; if (raw) fn(w, raw - 1, 0u); }
+        uint32_t raw = bits_at(f.v, w * g.c, g.c) + carry, code = 0;
+        if (raw > g.B) { uint32_t d = (1u << g.c) - raw; carry = 1; if (d) code = (d << 1) | 1u; }
+        else { carry = 0; if (raw) code = raw << 1; }
+        digits[(size_t)w * n + i] = code;
     }
 }
 
-__global__ void k_digits_count(const uint32_t *scalars, size_t n, int mont, int filter01, MsmGeom g,
-                               uint32_t *counts, uint32_t *ones_idx, uint32_t *n_ones) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ScalarRead s = read_scalar(scalars, i, mont, filter01);
-    if (s.cls == 0) return;
-    if (s.cls == 1) { ones_idx[atomicAdd(n_ones, 1u)] = (uint32_t)i; return; }
-    for_each_digit(s.v, g, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&counts[(size_t)w * g.B + b], 1u); });
+// ---- 2. per-(window, slice) histogram in LDS ---------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t *digits, size_t n, uint32_t B, uint32_t S, uint32_t slice_len, uint32_t *hist) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t s = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    for (uint32_t b = t; b < B; b += SORT_THREADS) lds_u32[b] = 0;
+    __syncthreads();
+    size_t lo = (size_t)s * slice_len, hi = lo + slice_len < n ? lo + slice_len : n;
+    const uint32_t *d = digits + (size_t)w * n;
+    for (size_t i = lo + t; i < hi; i += SORT_THREADS) { uint32_t code = d[i]; if (code) atomicAdd(&lds_u32[(code >> 1) - 1], 1u); }
+    __syncthreads();
+    uint32_t *out = hist + ((size_t)w * S + s) * B;
+    for (uint32_t b = t; b < B; b += SORT_THREADS) out[b] = lds_u32[b];
 }
 
-__global__ void k_scatter(const uint32_t *scalars, size_t n, int mont, int filter01, MsmGeom g,
-                          uint32_t *cursor, uint32_t *sorted) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ScalarRead s = read_scalar(scalars, i, mont, filter01);
-    if (s.cls != 2) return;
-    for_each_digit(s.v, g, [&](uint32_t w, uint32_t b, uint32_t neg) {
-        uint32_t pos = atomicAdd(&cursor[(size_t)w * g.B + b], 1u);
-        sorted[pos] = ((uint32_t)i << 1) | neg;
-    });
+// ---- 3. per-bucket totals; hist becomes the slice-relative offset inside its bucket -----------------------
+__global__ __launch_bounds__(256) void k_colscan(uint32_t *hist, uint32_t B, uint32_t S, size_t total, uint32_t *counts) {
+    size_t gb = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gb >= total) return;
+    uint32_t w = (uint32_t)(gb / B), b = (uint32_t)(gb % B), run = 0;
+    uint32_t *col = hist + (size_t)w * S * B + b;
+    for (uint32_t s = 0; s < S; ++s) { uint32_t v = col[(size_t)s * B]; col[(size_t)s * B] = run; run += v; }
+    counts[gb] = run;
 }
 
-// single-workgroup exclusive scan: offsets[i] = sum counts[<i]; cursor = copy; offsets[total] = sum
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, size_t total) {
+// block-wise exclusive scan (three launches): offsets[i] = sum counts[<i], offsets[total] = sum
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *in, uint32_t *out, uint32_t *sums, size_t total) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
-    size_t per = (total + 1023) / 1024, lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
-    uint32_t s = 0;
-    for (size_t i = lo; i < hi; ++i) s += counts[i];
+    size_t base = ((size_t)blockIdx.x * 1024 + t) * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = base + j < total ? in[base + j] : 0; s += v[j]; }
     part[t] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (t >= d) ? part[t - d] : 0;
+        uint32_t x = (t >= d) ? part[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
     uint32_t run = part[t] - s;
-    for (size_t i = lo; i < hi; ++i) { uint32_t c = counts[i]; offsets[i] = run; cursor[i] = run; run += c; }
-    if (t == 1023) offsets[total] = part[1023];
+    for (int j = 0; j < SCAN_ITEMS; ++j) { if (base + j < total) out[base + j] = run; run += v[j]; }
+    if (t == 1023) sums[blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *sums, uint32_t nblk, uint32_t *grand_total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t s = t < nblk ? sums[t] : 0;
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if (t < nblk) sums[t] = part[t] - s;
+    if (t == 1023) *grand_total = part[1023];
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t *out, const uint32_t *sums, size_t total) {
+    size_t base = ((size_t)blockIdx.x * 1024 + threadIdx.x) * SCAN_ITEMS;
+    uint32_t add = sums[blockIdx.x];
+    for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < total) out[base + j] += add;
 }
 
-// ---- bucket accumulation (dominant kernel) ---------------------------------------------------
+// ---- 4. placement: cursors of this (window, slice) staged in LDS -----------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_place(const uint32_t *digits, size_t n, uint32_t B, uint32_t S, uint32_t slice_len,
+                                                         const uint32_t *hist, const uint32_t *offsets, uint32_t *sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t s = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    const uint32_t *rel = hist + ((size_t)w * S + s) * B, *off = offsets + (size_t)w * B;
+    for (uint32_t b = t; b < B; b += SORT_THREADS) lds_u32[b] = off[b] + rel[b];
+    __syncthreads();
+    size_t lo = (size_t)s * slice_len, hi = lo + slice_len < n ? lo + slice_len : n;
+    const uint32_t *d = digits + (size_t)w * n;
+    for (size_t i = lo + t; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code) { uint32_t pos = atomicAdd(&lds_u32[(code >> 1) - 1], 1u); sorted[pos] = ((uint32_t)i << 1) | (code & 1u); }
+    }
+}
+
+// ---- 5. bucket order by descending length (classes 0..heavy_t, heavy_t+1 = heavy) ------------------------
+__global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, size_t total, uint32_t heavy_t, uint32_t *class_hist) {
+    __shared__ uint32_t h[HEAVY_T_MAX + 2];
+    const uint32_t t = threadIdx.x, nc = heavy_t + 2;
+    for (uint32_t i = t; i < nc; i += 1024) h[i] = 0;
+    __syncthreads();
+    size_t gb = (size_t)blockIdx.x * 1024 + t;
+    if (gb < total) { uint32_t c = counts[gb]; atomicAdd(&h[c > heavy_t ? heavy_t + 1 : c], 1u); }
+    __syncthreads();
+    for (uint32_t i = t; i < nc; i += 1024) if (h[i]) atomicAdd(&class_hist[i], h[i]);
+}
+__global__ void k_class_scan(uint32_t *class_hist, uint32_t heavy_t) {       // in place: start position of every class, longest first
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int c = (int)heavy_t + 1; c >= 0; --c) { uint32_t v = class_hist[c]; class_hist[c] = run; run += v; }
+}
+__global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, size_t total, uint32_t heavy_t, uint32_t *class_cursor, uint32_t *order) {
+    __shared__ uint32_t h[HEAVY_T_MAX + 2];
+    const uint32_t t = threadIdx.x, nc = heavy_t + 2;
+    for (uint32_t i = t; i < nc; i += 1024) h[i] = 0;
+    __syncthreads();
+    size_t gb = (size_t)blockIdx.x * 1024 + t;
+    uint32_t cls = 0, rank = 0;
+    if (gb < total) { uint32_t c = counts[gb]; cls = c > heavy_t ? heavy_t + 1 : c; rank = atomicAdd(&h[cls], 1u); }
+    __syncthreads();
+    for (uint32_t i = t; i < nc; i += 1024) if (h[i]) h[i] = atomicAdd(&class_cursor[i], h[i]);      // reserve a range per class
+    __syncthreads();
+    if (gb < total) order[h[cls] + rank] = (uint32_t)gb;
+}
+
+// ---- 6. bucket accumulation (dominant kernel) -------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, const uint32_t *sorted, const uint32_t *offsets,
-                                                       size_t total_buckets, XYZZ<F> *buckets,
+__global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+                                                       size_t total_buckets, uint32_t heavy_t, XYZZ<F> *buckets,
                                                        HeavyItem *items, HeavyBucket *heavy, uint32_t *counters /* [0] items, [1] heavy buckets */) {
-    size_t gb = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gb >= total_buckets) return;
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total_buckets) return;
+    const uint32_t gb = order[tid];
     uint32_t k = offsets[gb], end = offsets[gb + 1];
-    if (end - k > HEAVY_T) {
+    if (end - k > heavy_t) {
         uint32_t nparts = (end - k + HEAVY_S - 1) / HEAVY_S;
         uint32_t first = atomicAdd(&counters[0], nparts);
         for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end}; }
-        heavy[atomicAdd(&counters[1], 1u)] = {(uint32_t)gb, first, nparts};
+        heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
         return;
     }
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (; k < end; ++k) {
+    if (k < end) {
         uint32_t e = sorted[k];
         Affine<F> p = bases[e >> 1];
-        if (e & 1u) p.y = p.y.neg();
-        acc.madd(p);
+        while (true) {
+            Affine<F> cur = p; uint32_t ce = e;
+            ++k;
+            if (k < end) { e = sorted[k]; p = bases[e >> 1]; }            // prefetch the next base under this addition
+            if (ce & 1u) cur.y = cur.y.neg();
+            acc.madd(cur);
+            if (k >= end) break;
+        }
     }
     buckets[gb] = acc;
 }
@@ -200,7 +275,7 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
     }
 }
 
-// ---- bucket reduction: per chunk of RED_CHUNK buckets emit P = sum X_i and U = sum i*X_i (i 0-based in chunk)
+// ---- 7. bucket reduction: per chunk of RED_CHUNK buckets emit P = sum X_i and U = sum i*X_i (i 0-based in chunk)
 template <class F>
 __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out) {
     extern __shared__ unsigned char red_smem[];
@@ -245,46 +320,38 @@ __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *bu
     }
 }
 
-// ---- scalars == 1: plain sum of the selected bases
-template <class F>
-__global__ __launch_bounds__(256) void k_sum_ones(const Affine<F> *bases, const uint32_t *ones_idx, const uint32_t *n_ones, XYZZ<F> *out) {
-    extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
-    const uint32_t n = *n_ones, t = threadIdx.x, stride = gridDim.x * blockDim.x;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t k = blockIdx.x * blockDim.x + t; k < n; k += stride) acc.madd(bases[ones_idx[k]]);
-    sh[t] = acc;
-    __syncthreads();
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (t < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
-        __syncthreads();
-    }
-    if (t == 0) out[blockIdx.x] = sh[0];
-}
-
-// ---- workspace ------------------------------------------------------------------------------
+// ---- workspace ----------------------------------------------------------------------------------------
 struct MsmWorkspace {
-    DevBuf counts, offsets, cursor, sorted, ones_idx, n_ones, buckets, red_out, ones_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
-    std::vector<unsigned char> host_red, host_ones;
+    DevBuf digits, hist, counts, offsets, scan_sums, class_hist, class_cursor, order, sorted, buckets, red_out,
+           heavy_items, heavy_buckets, heavy_counters, heavy_partials;
+    std::vector<unsigned char> host_red;
     std::mutex mu;
 };
 static MsmWorkspace g_ws;
 
+static uint32_t heavy_threshold(size_t n, MsmGeom g) {
+    size_t avg = n / g.B, t = 4 * avg;
+    if (t < 256) t = 256;
+    if (t > HEAVY_T_MAX) t = HEAVY_T_MAX;
+    return (uint32_t)t;
+}
+
 template <class F>
-static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n_entries_max, size_t total_buckets, XYZZ<F> *out, hipStream_t s, bool time_it) {
+static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n, size_t total_buckets, XYZZ<F> *out, hipStream_t s, bool time_it) {
     MsmWorkspace &ws = g_ws;
-    size_t max_heavy = n_entries_max / HEAVY_T + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;
+    const uint32_t heavy_t = heavy_threshold(n, g);
+    size_t n_entries_max = n * g.W;
+    size_t max_heavy = n_entries_max / heavy_t + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;
     if (ws.heavy_items.reserve(max_items * sizeof(HeavyItem)) || ws.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
         ws.heavy_counters.reserve(8) || ws.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
     ZK_HIP(hipMemsetAsync(ws.heavy_counters.p, 0, 8, s));
     uint32_t cpw = (g.B + RED_CHUNK - 1) / RED_CHUNK;
     size_t nred = (size_t)g.W * cpw;
-    if (ws.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || ws.red_out.reserve(nred * 2 * sizeof(XYZZ<F>)) ||
-        ws.ones_out.reserve(ONES_BLOCKS * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    if (ws.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || ws.red_out.reserve(nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
     XYZZ<F> *buckets = ws.buckets.as<XYZZ<F>>();
     if (time_it) g_dominant_timer.begin(s);
     hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
-                       d_bases, ws.sorted.as<uint32_t>(), ws.offsets.as<uint32_t>(), total_buckets, buckets,
+                       d_bases, ws.sorted.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.order.as<uint32_t>(), total_buckets, heavy_t, buckets,
                        ws.heavy_items.as<HeavyItem>(), ws.heavy_buckets.as<HeavyBucket>(), ws.heavy_counters.as<uint32_t>());
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
@@ -293,12 +360,9 @@ static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n_e
                        ws.heavy_buckets.as<HeavyBucket>(), ws.heavy_counters.as<uint32_t>(), ws.heavy_partials.as<XYZZ<F>>(), buckets);
     hipLaunchKernelGGL(k_bucket_reduce<F>, dim3((unsigned)nred), dim3(RED_THREADS), 2 * RED_THREADS * sizeof(XYZZ<F>), s,
                        buckets, g.B, cpw, ws.red_out.as<XYZZ<F>>());
-    hipLaunchKernelGGL(k_sum_ones<F>, dim3(ONES_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       d_bases, ws.ones_idx.as<uint32_t>(), ws.n_ones.as<uint32_t>(), ws.ones_out.as<XYZZ<F>>());
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
-    ws.host_red.resize(nred * 2 * sizeof(XYZZ<F>)); ws.host_ones.resize(ONES_BLOCKS * sizeof(XYZZ<F>));
+    ws.host_red.resize(nred * 2 * sizeof(XYZZ<F>));
     ZK_HIP(hipMemcpyAsync(ws.host_red.data(), ws.red_out.p, ws.host_red.size(), hipMemcpyDeviceToHost, s));
-    ZK_HIP(hipMemcpyAsync(ws.host_ones.data(), ws.ones_out.p, ws.host_ones.size(), hipMemcpyDeviceToHost, s));
     ZK_HIP(hipStreamSynchronize(s));
     // host: window value V_w = sum_b (b+1) X_b = U_w + P_w, with chunk ch contributing
     //   U_ch + (ch*RED_CHUNK) * P_ch  to U_w and P_ch to P_w; then Horner over windows.
@@ -316,47 +380,57 @@ static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n_e
         for (int i = 0; i < 11; ++i) weighted = weighted.dbl();            // * RED_CHUNK (2048)
         acc.add(Usum); acc.add(weighted); acc.add(suffix);
     }
-    const XYZZ<F> *ones = reinterpret_cast<const XYZZ<F> *>(ws.host_ones.data());
-    for (int i = 0; i < ONES_BLOCKS; ++i) acc.add(ones[i]);
     *out = acc;
     return ZKG_OK;
 }
 static_assert(RED_CHUNK == 2048 && RED_L == 8, "host combine assumes 2048-bucket chunks");
 
-static int sort_digits(const uint32_t *d_scalars, size_t n, bool mont, bool filter01, MsmGeom g, hipStream_t s) {
+static int sort_digits(const uint32_t *d_scalars, size_t n, bool mont, MsmGeom g, hipStream_t s) {
     MsmWorkspace &ws = g_ws;
-    size_t total = (size_t)g.W * g.B;
-    if (ws.counts.reserve(total * 4) || ws.offsets.reserve((total + 1) * 4) || ws.cursor.reserve(total * 4) ||
-        ws.sorted.reserve(std::max<size_t>(1, n * g.W) * 4) || ws.ones_idx.reserve(std::max<size_t>(1, n) * 4) || ws.n_ones.reserve(4)) return ZKG_ERROR;
-    ZK_HIP(hipMemsetAsync(ws.counts.p, 0, total * 4, s));
-    ZK_HIP(hipMemsetAsync(ws.n_ones.p, 0, 4, s));
-    if (n) hipLaunchKernelGGL(k_digits_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, (int)filter01, g,
-                              ws.counts.as<uint32_t>(), ws.ones_idx.as<uint32_t>(), ws.n_ones.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, ws.counts.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>(), total);
-    if (n) hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, (int)filter01, g,
-                              ws.cursor.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    const size_t total = (size_t)g.W * g.B;
+    uint32_t slice_len = (uint32_t)std::min<size_t>(65536, std::max<size_t>(4096, ((n + 15) / 16 + 1023) / 1024 * 1024));
+    uint32_t S = (uint32_t)std::max<size_t>(1, (n + slice_len - 1) / slice_len);
+    const uint32_t heavy_t = heavy_threshold(n, g);
+    size_t nblk = (total + 1024 * SCAN_ITEMS - 1) / (1024 * SCAN_ITEMS);
+    if (nblk > 1024) { set_error("msm: too many buckets for the block scan"); return ZKG_ERROR; }
+    if (ws.digits.reserve(std::max<size_t>(1, n * g.W) * 4) || ws.hist.reserve((size_t)g.W * S * g.B * 4) || ws.counts.reserve(total * 4) ||
+        ws.offsets.reserve((total + 1) * 4) || ws.scan_sums.reserve(1024 * 4) || ws.class_hist.reserve((HEAVY_T_MAX + 2) * 4) ||
+        ws.class_cursor.reserve((HEAVY_T_MAX + 2) * 4) || ws.order.reserve(total * 4) || ws.sorted.reserve(std::max<size_t>(1, n * g.W) * 4)) return ZKG_ERROR;
+    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, g, ws.digits.as<uint32_t>());
+    hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, ws.digits.as<uint32_t>(), n, g.B, S, slice_len, ws.hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_colscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws.hist.as<uint32_t>(), g.B, S, total, ws.counts.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblk), dim3(1024), 0, s, ws.counts.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.scan_sums.as<uint32_t>(), total);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, ws.scan_sums.as<uint32_t>(), (uint32_t)nblk, ws.offsets.as<uint32_t>() + total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, ws.offsets.as<uint32_t>(), ws.scan_sums.as<uint32_t>(), total);
+    hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, ws.digits.as<uint32_t>(), n, g.B, S, slice_len,
+                       ws.hist.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    ZK_HIP(hipMemsetAsync(ws.class_hist.p, 0, (HEAVY_T_MAX + 2) * 4, s));
+    hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, ws.counts.as<uint32_t>(), total, heavy_t, ws.class_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, ws.class_hist.as<uint32_t>(), heavy_t);
+    hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, ws.counts.as<uint32_t>(), total, heavy_t,
+                       ws.class_hist.as<uint32_t>(), ws.order.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) { set_error("msm sort launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
 
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, bool filter01, G1 *out_g1, G2 *out_g2, hipStream_t s) {
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_ws.mu);
     if (n >= ((size_t)1 << 31)) { set_error("msm: n too large"); return ZKG_ERROR; }
     MsmGeom g = pick_geom(n);
     size_t total = (size_t)g.W * g.B;
-    if (sort_digits(d_scalars, n, scalars_mont, filter01, g, s)) return ZKG_ERROR;
+    if (sort_digits(d_scalars, n, scalars_mont, g, s)) return ZKG_ERROR;
     for (int i = 0; i < n_g1; ++i)
-        if (accumulate_and_reduce<Fq>(d_g1_bases[i], g, n * g.W, total, &out_g1[i], s, true)) return ZKG_ERROR;
-    if (d_g2_bases && accumulate_and_reduce<Fq2>(d_g2_bases, g, n * g.W, total, out_g2, s, n_g1 == 0)) return ZKG_ERROR;
+        if (accumulate_and_reduce<Fq>(d_g1_bases[i], g, n, total, &out_g1[i], s, true)) return ZKG_ERROR;
+    if (d_g2_bases && accumulate_and_reduce<Fq2>(d_g2_bases, g, n, total, out_g2, s, n_g1 == 0)) return ZKG_ERROR;
     return ZKG_OK;
 }
 
-int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, bool filter01, G1 *out, hipStream_t s) {
-    return msm_shared(&d_bases, 1, nullptr, d_scalars, n, mont, filter01, out, nullptr, s);
+int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
+    return msm_shared(&d_bases, 1, nullptr, d_scalars, n, mont, out, nullptr, s);
 }
-int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, bool filter01, G2 *out, hipStream_t s) {
-    return msm_shared(nullptr, 0, d_bases, d_scalars, n, mont, filter01, nullptr, out, s);
+int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G2 *out, hipStream_t s) {
+    return msm_shared(nullptr, 0, d_bases, d_scalars, n, mont, nullptr, out, s);
 }
 
 // ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
@@ -393,15 +467,17 @@ int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2A
 int msm_configure() {
     bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_THREADS * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_THREADS * (int)sizeof(G1)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_sum_ones<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 void msm_release_all() {
     MsmWorkspace &ws = g_ws;
     std::lock_guard<std::mutex> lk(ws.mu);
-    for (DevBuf *b : {&ws.counts, &ws.offsets, &ws.cursor, &ws.sorted, &ws.ones_idx, &ws.n_ones, &ws.buckets, &ws.red_out, &ws.ones_out, &ws.heavy_items, &ws.heavy_buckets, &ws.heavy_counters, &ws.heavy_partials}) b->release();
+    for (DevBuf *b : {&ws.digits, &ws.hist, &ws.counts, &ws.offsets, &ws.scan_sums, &ws.class_hist, &ws.class_cursor, &ws.order, &ws.sorted, &ws.buckets,
+                      &ws.red_out, &ws.heavy_items, &ws.heavy_buckets, &ws.heavy_counters, &ws.heavy_partials}) b->release();
 }
 
 }  // namespace zk

@@ -201,11 +201,11 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     const uint32_t *z = crs->z.as<uint32_t>();
     const G1Affine *g1sets[2] = {crs->A_query.as<G1Affine>(), crs->B_g1.as<G1Affine>()};
     G1 AB[2]; G2 Bt2; G1 Ht, Lt;
-    if (msm_shared(g1sets, 2, crs->B_g2.as<G2Affine>(), z, n + 1, true, true, AB, &Bt2, s)) return ZKG_ERROR;
+    if (msm_shared(g1sets, 2, crs->B_g2.as<G2Affine>(), z, n + 1, true, AB, &Bt2, s)) return ZKG_ERROR;
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[3], s);
-    if (msm_g1(crs->H_query.as<G1Affine>(), crs->aA.as<uint32_t>(), m - 1, true, true, &Ht, s)) return ZKG_ERROR;
+    if (msm_g1(crs->H_query.as<G1Affine>(), crs->aA.as<uint32_t>(), m - 1, true, &Ht, s)) return ZKG_ERROR;
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[4], s);
-    if (msm_g1(crs->L_query.as<G1Affine>(), z + 8 * (l + 1), n - l, true, true, &Lt, s)) return ZKG_ERROR;
+    if (msm_g1(crs->L_query.as<G1Affine>(), z + 8 * (l + 1), n - l, true, &Lt, s)) return ZKG_ERROR;
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[5], s);
     // ---- assembly (host; a handful of scalar multiplications)
     Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
