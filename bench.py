@@ -49,6 +49,96 @@ def splitmix_fr(n, seed):
     return np.ascontiguousarray(out[:n])
 
 
+G2_GEN_MONT = np.array([0x8e83b5d102bc2026, 0xdceb1935497b0172, 0xfbb8264797811adf, 0x19573841af96503b,
+                        0xafb4737da84c6140, 0x6043dd5a5802d8c4, 0x09e950fc52a02f86, 0x14fef0833aea7b6b,
+                        0x619dfa9d886be9f6, 0xfe7fd297f59e9b78, 0xff9e1a62231b7dfe, 0x28fd7eebae9e4206,
+                        0x64095b56c71856ee, 0xdc57f922327d3cbb, 0x55f935be33351076, 0x0da4a0e693fd6482], dtype=np.uint64)
+
+
+def extras(zkg, torch, args, with_cpu):
+    """Secondary legs of the metric, single GPU: NTT 2^20 (BASELINE configs[2]) and a full Groth16 prove on a zklaim-shaped
+    system padded to m = 2^logm (configs[3]); not part of `value`."""
+    out = {}
+    # ---- NTT 2^20 forward + inverse, resident
+    logn = 20; n = 1 << logn
+    a = splitmix_fr(n, SEED + 3)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    for inv in (False, True):
+        zkg.ntt_dev(d_a.data_ptr(), logn, inverse=inv)
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        zkg.ntt_dev(d_a.data_ptr(), logn, inverse=False); zkg.ntt_dev(d_a.data_ptr(), logn, inverse=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (2 * reps)
+    roundtrip_ok = bool(np.array_equal(d_a.cpu().numpy().view(np.uint64), a))
+    out["ntt_2p20"] = {"ms_per_transform": round(dt * 1e3, 4), "GBps_algorithmic": round(64 * n / dt / 1e9, 2), "bytes_per_element": 64,
+                       "frac_of_hbm_peak": round(64 * n / dt / 1e9 / HBM_PEAK_GBPS, 5), "forward_inverse_roundtrip_exact": roundtrip_ok}
+
+    # ---- Groth16 prove, m = 2^logm, synthetic zklaim-shaped R1CS, synthetic CRS (queries = k_i*G built on device)
+    from zklaim_amd import synth
+    logm = args.prove_logm
+    t_syn = time.perf_counter()
+    nv, l, A, B, C, w = synth.zklaim_shaped(logm, num_inputs=41, seed=4)
+    m = 1 << logm
+
+    def g1_points(cnt, seed):
+        ks = splitmix_fr(cnt, seed); d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+        o = torch.empty((cnt, 8), dtype=torch.int64, device="cuda")
+        zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), cnt, o.data_ptr()); torch.cuda.synchronize()
+        return o.cpu().numpy().view(np.uint64)
+
+    def g2_points(cnt, seed):
+        ks = splitmix_fr(cnt, seed); d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+        o = torch.empty((cnt, 16), dtype=torch.int64, device="cuda")
+        zkg.fixed_base_g2_dev(G2_GEN_MONT, d_k.data_ptr(), cnt, o.data_ptr()); torch.cuda.synchronize()
+        return o.cpu().numpy().view(np.uint64)
+
+    small1 = g1_points(3, SEED + 0x40); small2 = g2_points(2, SEED + 0x41)
+    arrays = dict(alpha_g1=small1[0], beta_g1=small1[1], delta_g1=small1[2], beta_g2=small2[0], delta_g2=small2[1],
+                  A_query=g1_points(nv + 1, SEED + 0x42), B_g1=g1_points(nv + 1, SEED + 0x43), B_g2=g2_points(nv + 1, SEED + 0x44),
+                  H_query=g1_points(m - 1, SEED + 0x45), L_query=g1_points(nv - l, SEED + 0x46))
+    keep = []
+    cs = zkg.make_r1cs(nv, l, A, B, C, keep)
+    pk = zkg.make_pk(cs, arrays, logm, keep)
+    crs = zkg.Crs(pk)
+    rs = splitmix_fr(2, SEED + 5)
+    setup_s = time.perf_counter() - t_syn
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc == 0, "synthetic system must be satisfiable"
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rc, proof2 = crs.prove(w, rs[0], rs[1])
+    dt = (time.perf_counter() - t0) / reps
+    nnz = int(len(A[1]) + len(B[1]) + len(C[1]))
+    alg_bytes = 7 * 64 * m + 96 * (nv + 1) + (128 + 64 + 32) * (nv + 1) + 96 * (m - 1) + 96 * (nv - l)
+    g = {"log_m": logm, "num_variables": int(nv), "num_inputs": int(l), "num_constraints": int(m - l - 1), "nnz": nnz,
+         "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3), "algorithmic_bytes_per_proof": int(alg_bytes),
+         "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
+         "stage_names": ["r1cs_matvec", "7_ntt+pointwise", "msm_A+B1+B2", "-", "-", "msm_H", "msm_L", "total_incl_host_assembly"],
+         "setup_seconds_excluded": round(setup_s, 1), "deterministic": proof2 == proof,
+         "crs": "synthetic: query points k_i*G from SplitMix64 scalars (timing and GPU-vs-CPU byte parity do not need a trapdoor-consistent CRS)"}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import zkoracle
+        okeep = []
+        ocs = zkoracle.make_r1cs(nv, l, A, B, C, okeep)
+        arrays["m"] = m
+        opk = zkoracle.make_pk(ocs, arrays)
+        t1 = time.perf_counter()
+        rc_o, proof_o = zkoracle.groth16_prove(opk, w, rs[0], rs[1], True, 1)
+        cpu_dt = time.perf_counter() - t1
+        g["cpu_baseline"] = {"proofs_per_sec": round(1.0 / cpu_dt, 4), "seconds": round(cpu_dt, 2), "cores": 1, "kind": "port",
+                             "sample": "one full prove of the same system, oracle restatement of r1cs_gg_ppzksnark_prover, single thread"}
+        g["proof_bytes_match_cpu"] = bool(rc_o == 0 and proof_o == proof)
+        g["speedup_vs_cpu_1core"] = round(cpu_dt / dt, 1)
+    crs.free()
+    out["groth16_prove"] = g
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +146,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOGN, help="log2 points per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
+    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg (BASELINE configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +243,8 @@ def main():
                                           f"({cpu_dt:.2f} s) — mirrors the reference default MULTICORE=OFF",
                                 "value_all_cores": round(BYTES_PER_POINT * sample_n / cpu_dt_mt / 1e9, 5), "cores_all": threads,
                                 "seconds_all_cores": round(cpu_dt_mt, 3), "gpu_matches_cpu": parity and bool(np.array_equal(ref_mt, ref))}
+    if rank == 0 and world == 1 and not args.no_extras:
+        line["extras"] = extras(zkg, torch, args, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
