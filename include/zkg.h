@@ -135,9 +135,10 @@ int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_
                       const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */
 int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_out);
-/* per-stage device milliseconds of the last zkg_groth16_prove on this crs:
- * [0] R1CS mat-vec, [1] 7 NTTs + pointwise, [2] MSMs A + B(G1) + B(G2) (one shared digit sort),
- * [3] 0, [4] 0, [5] MSM H, [6] MSM L, [7] total incl. host assembly                     */
+/* per-stage device milliseconds of the last zkg_groth16_prove on this crs (the five MSMs run
+ * concurrently on their own streams, so the entries overlap and do not add up to the total):
+ * [0] R1CS mat-vec, [1] 7 NTTs + pointwise, [2] MSM A, [3] MSM B(G1), [4] MSM B(G2), [5] MSM H,
+ * [6] MSM L, [7] wall-clock total incl. host assembly                                  */
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
 
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
 #include "curve.cuh"
 
 namespace zk {
@@ -39,6 +41,9 @@ struct NttDomain {
     DevBuf icoset_post;           // g^-i / N          (icosetFFT post-multiplication, 1/N folded in)
     DevBuf scratch;               // N elements
     Fr n_inv;                     // 1/N
+    std::mutex mu; bool first_stream_set = false; hipStream_t first_stream = nullptr;
+    std::map<hipStream_t, DevBuf> stream_scratch;
+    Fr *scratch_for(hipStream_t s);
     int init(unsigned logn, hipStream_t s);
     void release();
 };
@@ -46,14 +51,18 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s);     // cached per size
 // mode: inverse / coset as in zkg_ntt.  extra_post (device, N Fr, optional) replaces the default
 // post table: the prover fuses iFFT's 1/N with the following cosetFFT's g^i through it.
 int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s);
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s);
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr);
 int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s);   // out[i] = scale * base^i
 void ntt_release_all();
 int ntt_configure();
 
 // ---------------- MSM (msm.hip) ----------------
-struct MsmPlan;                                            // per-(curve,N) workspace + sorted digit lists
-template <class F> struct MsmResult { XYZZ<F> value; };
+struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
+MsmJob *msm_job_create(hipStream_t s, bool own_stream);
+hipStream_t msm_job_stream(MsmJob *j);
+void msm_job_destroy(MsmJob *j);
+int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);
+int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);
 // scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  Zero scalars are dropped and ones land in
 // one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s);

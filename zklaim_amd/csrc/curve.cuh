@@ -27,13 +27,14 @@ template <class F> struct Affine {
 
 template <class F> struct XYZZ {
     F x, y, zz, zzz;
+    static constexpr bool kInlineAll = sizeof(F) == sizeof(Fq);       // G1: everything inline; G2: group ops out of line
     static ZK_HD XYZZ inf() { return {F::zero(), F::one(), F::zero(), F::zero()}; }
     static ZK_HD XYZZ from_affine(const Affine<F> &a) { return a.is_inf() ? inf() : XYZZ{a.x, a.y, F::one(), F::one()}; }
     ZK_HD bool is_inf() const { return zz.is_zero(); }
     ZK_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
 
     // dbl-2008-s-1
-    ZK_HD_NOINLINE XYZZ dbl() const {
+    ZK_HD XYZZ dbl_inl() const {
         if (is_inf()) return *this;
         F U = y.dbl(), V = U.sqr(), W = U * V, S = x * V;
         F xx = x.sqr(), M = xx.dbl() + xx;
@@ -41,22 +42,35 @@ template <class F> struct XYZZ {
         F Y3 = M * (S - X3) - W * y;
         return {X3, Y3, V * zz, W * zzz};
     }
+    ZK_HD_NOINLINE XYZZ dbl_out() const { return dbl_inl(); }
+    ZK_HD XYZZ dbl() const { if constexpr (kInlineAll) return dbl_inl(); else return dbl_out(); }
+
     // doubling of an affine point (mdbl-2008-s-1)
-    static ZK_HD_NOINLINE XYZZ dbl_affine(const Affine<F> &a) {
+    static ZK_HD XYZZ dbl_affine_inl(const Affine<F> &a) {
         F U = a.y.dbl(), V = U.sqr(), W = U * V, S = a.x * V;
         F xx = a.x.sqr(), M = xx.dbl() + xx;
         F X3 = M.sqr() - S.dbl();
         F Y3 = M * (S - X3) - W * a.y;
         return {X3, Y3, V, W};
     }
-    // madd-2008-s, with the exceptional cases (this == inf, b == inf, b == +-this) handled
+    static ZK_HD_NOINLINE XYZZ dbl_affine_out(const Affine<F> &a) { return dbl_affine_inl(a); }
+
+    // madd-2008-s, with the exceptional cases (this == inf, b == inf, b == +-this) handled.  The accumulator must stay in
+    // registers across the hot loop, so the rare doubling branch works on private copies: nothing that lives across
+    // iterations ever has its address taken (an escaped address parks the whole accumulator in scratch memory —
+    // measured as 2 GB of extra HBM writes per 2^20-point MSM).
     ZK_HD void madd(const Affine<F> &b) {
         if (b.is_inf()) return;
-        if (is_inf()) { *this = {b.x, b.y, F::one(), F::one()}; return; }
+        if (is_inf()) { x = b.x; y = b.y; zz = F::one(); zzz = F::one(); return; }
         F U2 = b.x * zz, S2 = b.y * zzz;
         F P = U2 - x, R = S2 - y;
-        if (P.is_zero()) {
-            if (R.is_zero()) *this = dbl_affine(b); else *this = inf();
+        if (__builtin_expect(P.is_zero(), 0)) {
+            if (R.is_zero()) {
+                XYZZ t;
+                if constexpr (kInlineAll) t = dbl_affine_inl(b);
+                else { Affine<F> bc = {b.x, b.y}; t = dbl_affine_out(bc); }
+                x = t.x; y = t.y; zz = t.zz; zzz = t.zzz;
+            } else { x = F::zero(); y = F::one(); zz = F::zero(); zzz = F::zero(); }
             return;
         }
         F PP = P.sqr(), PPP = P * PP, Q = x * PP;
@@ -65,13 +79,13 @@ template <class F> struct XYZZ {
         x = X3; y = Y3; zz = zz * PP; zzz = zzz * PPP;
     }
     // add-2008-s, exceptional cases handled
-    ZK_HD_NOINLINE void add(const XYZZ &b) {
+    ZK_HD void add_inl(const XYZZ &b) {
         if (b.is_inf()) return;
         if (is_inf()) { *this = b; return; }
         F U1 = x * b.zz, U2 = b.x * zz, S1 = y * b.zzz, S2 = b.y * zzz;
         F P = U2 - U1, R = S2 - S1;
-        if (P.is_zero()) {
-            if (R.is_zero()) *this = dbl(); else *this = inf();
+        if (__builtin_expect(P.is_zero(), 0)) {
+            if (R.is_zero()) { XYZZ t = dbl(); x = t.x; y = t.y; zz = t.zz; zzz = t.zzz; } else *this = inf();
             return;
         }
         F PP = P.sqr(), PPP = P * PP, Q = U1 * PP;
@@ -79,10 +93,13 @@ template <class F> struct XYZZ {
         F Y3 = R * (Q - X3) - S1 * PPP;
         x = X3; y = Y3; zz = zz * b.zz * PP; zzz = zzz * b.zzz * PPP;
     }
+    ZK_HD_NOINLINE void add_out(const XYZZ &b) { add_inl(b); }
+    ZK_HD void add(const XYZZ &b) { if constexpr (kInlineAll) add_inl(b); else add_out(b); }
+
     ZK_HD_NOINLINE Affine<F> to_affine() const {
         if (is_inf()) return Affine<F>::inf();
-        F zi = zzz.inverse();              // 1/ZZZ ;  1/ZZ = ZZZ^-2 * ZZ^2 ... use x = X * (zi*ZZ)^2
-        F t = zi * zz;                     // = ZZ/ZZZ = 1/Z
+        F zi = zzz.inverse();              // 1/ZZZ
+        F t = zi * zz;                     // ZZ/ZZZ = 1/Z
         F zi2 = t.sqr();                   // 1/ZZ
         return {x * zi2, y * zi};
     }

@@ -320,53 +320,70 @@ __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *bu
     }
 }
 
-// ---- workspace ----------------------------------------------------------------------------------------
-struct MsmWorkspace {
-    DevBuf digits, hist, counts, offsets, scan_sums, class_hist, class_cursor, order, sorted, buckets, red_out,
-           heavy_items, heavy_buckets, heavy_counters, heavy_partials;
-    std::vector<unsigned char> host_red;
+// ---- jobs: one MSM (or several base sets over one scalar vector) in flight on one stream ---------------------
+struct MsmSlot {                    // per base set: accumulators and the host landing zone of its chunk results
+    DevBuf buckets, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
+    void *host_red = nullptr; size_t host_cap = 0; bool g2 = false;
+    int host_reserve(size_t bytes) {
+        if (bytes <= host_cap) return 0;
+        if (host_red) (void)hipHostFree(host_red);
+        host_red = nullptr; host_cap = 0;
+        if (!hip_ok(hipHostMalloc(&host_red, bytes + 4096, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return 1;
+        host_cap = bytes + 4096;
+        return 0;
+    }
+    void release() {
+        for (DevBuf *b : {&buckets, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials}) b->release();
+        if (host_red) (void)hipHostFree(host_red);
+        host_red = nullptr; host_cap = 0;
+    }
+};
+struct MsmJob {
+    hipStream_t stream = nullptr; bool own_stream = false;
+    DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted;
+    MsmSlot slot[3]; int nslots = 0;
+    MsmGeom g{}; size_t n = 0; uint32_t cpw = 0; size_t nred = 0;
     std::mutex mu;
 };
-static MsmWorkspace g_ws;
 
-static uint32_t heavy_threshold(size_t n, MsmGeom g) {
-    size_t avg = n / g.B, t = 4 * avg;
-    if (t < 256) t = 256;
-    if (t > HEAVY_T_MAX) t = HEAVY_T_MAX;
-    return (uint32_t)t;
-}
+static uint32_t heavy_threshold(size_t n, MsmGeom g);
 
 template <class F>
-static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n, size_t total_buckets, XYZZ<F> *out, hipStream_t s, bool time_it) {
-    MsmWorkspace &ws = g_ws;
-    const uint32_t heavy_t = heavy_threshold(n, g);
+static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases, bool time_it) {
+    const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B;
+    hipStream_t s = job->stream;
+    uint32_t heavy_t = heavy_threshold(n, g);
+    if (sizeof(F) > sizeof(Fq)) heavy_t = heavy_t / 3 < 32 ? 32 : heavy_t / 3;      // a G2 addition costs ~3x a G1 addition: cut lists sooner
     size_t n_entries_max = n * g.W;
     size_t max_heavy = n_entries_max / heavy_t + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;
-    if (ws.heavy_items.reserve(max_items * sizeof(HeavyItem)) || ws.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
-        ws.heavy_counters.reserve(8) || ws.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    ZK_HIP(hipMemsetAsync(ws.heavy_counters.p, 0, 8, s));
-    uint32_t cpw = (g.B + RED_CHUNK - 1) / RED_CHUNK;
-    size_t nred = (size_t)g.W * cpw;
-    if (ws.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || ws.red_out.reserve(nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    XYZZ<F> *buckets = ws.buckets.as<XYZZ<F>>();
+    if (sl.heavy_items.reserve(max_items * sizeof(HeavyItem)) || sl.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
+        sl.heavy_counters.reserve(8) || sl.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    ZK_HIP(hipMemsetAsync(sl.heavy_counters.p, 0, 8, s));
+    if (sl.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || sl.red_out.reserve(job->nred * 2 * sizeof(XYZZ<F>)) ||
+        sl.host_reserve(job->nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    XYZZ<F> *buckets = sl.buckets.as<XYZZ<F>>();
     if (time_it) g_dominant_timer.begin(s);
     hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
-                       d_bases, ws.sorted.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.order.as<uint32_t>(), total_buckets, heavy_t, buckets,
-                       ws.heavy_items.as<HeavyItem>(), ws.heavy_buckets.as<HeavyBucket>(), ws.heavy_counters.as<uint32_t>());
+                       d_bases, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, heavy_t, buckets,
+                       sl.heavy_items.as<HeavyItem>(), sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>());
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       d_bases, ws.sorted.as<uint32_t>(), ws.heavy_items.as<HeavyItem>(), ws.heavy_counters.as<uint32_t>(), ws.heavy_partials.as<XYZZ<F>>());
+                       d_bases, job->sorted.as<uint32_t>(), sl.heavy_items.as<HeavyItem>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>());
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       ws.heavy_buckets.as<HeavyBucket>(), ws.heavy_counters.as<uint32_t>(), ws.heavy_partials.as<XYZZ<F>>(), buckets);
-    hipLaunchKernelGGL(k_bucket_reduce<F>, dim3((unsigned)nred), dim3(RED_THREADS), 2 * RED_THREADS * sizeof(XYZZ<F>), s,
-                       buckets, g.B, cpw, ws.red_out.as<XYZZ<F>>());
+                       sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>(), buckets);
+    hipLaunchKernelGGL(k_bucket_reduce<F>, dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_THREADS * sizeof(XYZZ<F>), s,
+                       buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
-    ws.host_red.resize(nred * 2 * sizeof(XYZZ<F>));
-    ZK_HIP(hipMemcpyAsync(ws.host_red.data(), ws.red_out.p, ws.host_red.size(), hipMemcpyDeviceToHost, s));
-    ZK_HIP(hipStreamSynchronize(s));
-    // host: window value V_w = sum_b (b+1) X_b = U_w + P_w, with chunk ch contributing
-    //   U_ch + (ch*RED_CHUNK) * P_ch  to U_w and P_ch to P_w; then Horner over windows.
-    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(ws.host_red.data());
+    ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, job->nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+    return ZKG_OK;
+}
+
+// host: window value V_w = sum_b (b+1) X_b = U_w + P_w, with chunk ch contributing U_ch + (ch*RED_CHUNK) * P_ch to U_w
+// and P_ch to P_w; then Horner over windows (c doublings each).
+template <class F>
+static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
+    const MsmGeom g = job->g; const uint32_t cpw = job->cpw;
+    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(sl.host_red);
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int w = (int)g.W - 1; w >= 0; --w) {
         for (uint32_t i = 0; i < g.c; ++i) acc = acc.dbl();
@@ -380,50 +397,103 @@ static int accumulate_and_reduce(const Affine<F> *d_bases, MsmGeom g, size_t n, 
         for (int i = 0; i < 11; ++i) weighted = weighted.dbl();            // * RED_CHUNK (2048)
         acc.add(Usum); acc.add(weighted); acc.add(suffix);
     }
-    *out = acc;
-    return ZKG_OK;
+    return acc;
 }
 static_assert(RED_CHUNK == 2048 && RED_L == 8, "host combine assumes 2048-bucket chunks");
 
-static int sort_digits(const uint32_t *d_scalars, size_t n, bool mont, MsmGeom g, hipStream_t s) {
-    MsmWorkspace &ws = g_ws;
+// A lane walks its bucket's list alone, ~7 us per G1 addition at low occupancy, so the longest non-heavy list bounds the
+// kernel's latency however little total work there is: cut lists at a few times the average length (the partly filled
+// top window of uniform scalars averages ~2.7x the other windows and should stay on the lane-per-bucket path).
+static uint32_t heavy_threshold(size_t n, MsmGeom g) {
+    size_t avg = n / g.B, t = 4 * avg + 32;
+    if (t < 64) t = 64;
+    if (t > HEAVY_T_MAX) t = HEAVY_T_MAX;
+    return (uint32_t)t;
+}
+
+static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
+    const MsmGeom g = job->g; const size_t n = job->n;
+    hipStream_t s = job->stream;
     const size_t total = (size_t)g.W * g.B;
     uint32_t slice_len = (uint32_t)std::min<size_t>(65536, std::max<size_t>(4096, ((n + 15) / 16 + 1023) / 1024 * 1024));
     uint32_t S = (uint32_t)std::max<size_t>(1, (n + slice_len - 1) / slice_len);
     const uint32_t heavy_t = heavy_threshold(n, g);
     size_t nblk = (total + 1024 * SCAN_ITEMS - 1) / (1024 * SCAN_ITEMS);
     if (nblk > 1024) { set_error("msm: too many buckets for the block scan"); return ZKG_ERROR; }
-    if (ws.digits.reserve(std::max<size_t>(1, n * g.W) * 4) || ws.hist.reserve((size_t)g.W * S * g.B * 4) || ws.counts.reserve(total * 4) ||
-        ws.offsets.reserve((total + 1) * 4) || ws.scan_sums.reserve(1024 * 4) || ws.class_hist.reserve((HEAVY_T_MAX + 2) * 4) ||
-        ws.class_cursor.reserve((HEAVY_T_MAX + 2) * 4) || ws.order.reserve(total * 4) || ws.sorted.reserve(std::max<size_t>(1, n * g.W) * 4)) return ZKG_ERROR;
-    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, g, ws.digits.as<uint32_t>());
-    hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, ws.digits.as<uint32_t>(), n, g.B, S, slice_len, ws.hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_colscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws.hist.as<uint32_t>(), g.B, S, total, ws.counts.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblk), dim3(1024), 0, s, ws.counts.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.scan_sums.as<uint32_t>(), total);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, ws.scan_sums.as<uint32_t>(), (uint32_t)nblk, ws.offsets.as<uint32_t>() + total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, ws.offsets.as<uint32_t>(), ws.scan_sums.as<uint32_t>(), total);
-    hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, ws.digits.as<uint32_t>(), n, g.B, S, slice_len,
-                       ws.hist.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.sorted.as<uint32_t>());
-    ZK_HIP(hipMemsetAsync(ws.class_hist.p, 0, (HEAVY_T_MAX + 2) * 4, s));
-    hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, ws.counts.as<uint32_t>(), total, heavy_t, ws.class_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, ws.class_hist.as<uint32_t>(), heavy_t);
-    hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, ws.counts.as<uint32_t>(), total, heavy_t,
-                       ws.class_hist.as<uint32_t>(), ws.order.as<uint32_t>());
+    if (job->digits.reserve(std::max<size_t>(1, n * g.W) * 4) || job->hist.reserve((size_t)g.W * S * g.B * 4) || job->counts.reserve(total * 4) ||
+        job->offsets.reserve((total + 1) * 4) || job->scan_sums.reserve(1024 * 4) || job->class_hist.reserve((HEAVY_T_MAX + 2) * 4) ||
+        job->order.reserve(total * 4) || job->sorted.reserve(std::max<size_t>(1, n * g.W) * 4)) return ZKG_ERROR;
+    uint32_t *digits = job->digits.as<uint32_t>(), *hist = job->hist.as<uint32_t>(), *counts = job->counts.as<uint32_t>(),
+             *offsets = job->offsets.as<uint32_t>(), *sums = job->scan_sums.as<uint32_t>(), *chist = job->class_hist.as<uint32_t>();
+    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, g, digits);
+    hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist);
+    hipLaunchKernelGGL(k_colscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hist, g.B, S, total, counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblk), dim3(1024), 0, s, counts, offsets, sums, total);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, (uint32_t)nblk, offsets + total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, offsets, sums, total);
+    hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist, offsets, job->sorted.as<uint32_t>());
+    ZK_HIP(hipMemsetAsync(chist, 0, (HEAVY_T_MAX + 2) * 4, s));
+    hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, total, heavy_t, chist);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, chist, heavy_t);
+    hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, total, heavy_t, chist, job->order.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) { set_error("msm sort launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
 
+MsmJob *msm_job_create(hipStream_t s, bool own_stream) {
+    MsmJob *j = new MsmJob();
+    j->stream = s;
+    if (own_stream) {
+        if (!hip_ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__)) { delete j; return nullptr; }
+        j->own_stream = true;
+    }
+    return j;
+}
+hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
+void msm_job_destroy(MsmJob *j) {
+    if (!j) return;
+    for (DevBuf *b : {&j->digits, &j->hist, &j->counts, &j->offsets, &j->scan_sums, &j->class_hist, &j->order, &j->sorted}) b->release();
+    for (auto &sl : j->slot) sl.release();
+    if (j->own_stream) (void)hipStreamDestroy(j->stream);
+    delete j;
+}
+
+// enqueue: one digit sort of `d_scalars`, then one accumulate+reduce per base set (<= 2 G1 sets and <= 1 G2 set)
+int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont) {
+    if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
+    job->g = pick_geom(n); job->n = n;
+    job->cpw = (job->g.B + RED_CHUNK - 1) / RED_CHUNK; job->nred = (size_t)job->g.W * job->cpw;
+    if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
+    job->nslots = 0;
+    for (int i = 0; i < n_g1; ++i) {
+        MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = false;
+        if (launch_accumulate<Fq>(job, sl, d_g1_bases[i], true)) return ZKG_ERROR;
+    }
+    if (d_g2_bases) {
+        MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = true;
+        if (launch_accumulate<Fq2>(job, sl, d_g2_bases, n_g1 == 0)) return ZKG_ERROR;
+    }
+    return ZKG_OK;
+}
+// wait for the job's stream and finish on the host; outputs in launch order (G1 sets, then the G2 set)
+int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
+    ZK_HIP(hipStreamSynchronize(job->stream));
+    int k = 0;
+    for (int i = 0; i < job->nslots; ++i) {
+        if (job->slot[i].g2) *out_g2 = host_combine<Fq2>(job, job->slot[i]);
+        else out_g1[k++] = host_combine<Fq>(job, job->slot[i]);
+    }
+    return ZKG_OK;
+}
+
+static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex)
+
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_ws.mu);
-    if (n >= ((size_t)1 << 31)) { set_error("msm: n too large"); return ZKG_ERROR; }
-    MsmGeom g = pick_geom(n);
-    size_t total = (size_t)g.W * g.B;
-    if (sort_digits(d_scalars, n, scalars_mont, g, s)) return ZKG_ERROR;
-    for (int i = 0; i < n_g1; ++i)
-        if (accumulate_and_reduce<Fq>(d_g1_bases[i], g, n, total, &out_g1[i], s, true)) return ZKG_ERROR;
-    if (d_g2_bases && accumulate_and_reduce<Fq2>(d_g2_bases, g, n, total, out_g2, s, n_g1 == 0)) return ZKG_ERROR;
-    return ZKG_OK;
+    std::lock_guard<std::mutex> lk(g_default_job.mu);
+    g_default_job.stream = s;
+    if (msm_job_launch(&g_default_job, d_g1_bases, n_g1, d_g2_bases, d_scalars, n, scalars_mont)) return ZKG_ERROR;
+    return msm_job_finish(&g_default_job, out_g1, out_g2);
 }
 
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
@@ -474,10 +544,10 @@ int msm_configure() {
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 void msm_release_all() {
-    MsmWorkspace &ws = g_ws;
-    std::lock_guard<std::mutex> lk(ws.mu);
-    for (DevBuf *b : {&ws.digits, &ws.hist, &ws.counts, &ws.offsets, &ws.scan_sums, &ws.class_hist, &ws.class_cursor, &ws.order, &ws.sorted, &ws.buckets,
-                      &ws.red_out, &ws.heavy_items, &ws.heavy_buckets, &ws.heavy_counters, &ws.heavy_partials}) b->release();
+    MsmJob &j = g_default_job;
+    std::lock_guard<std::mutex> lk(j.mu);
+    for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted}) b->release();
+    for (auto &sl : j.slot) sl.release();
 }
 
 }  // namespace zk

@@ -130,7 +130,20 @@ int NttDomain::init(unsigned logn_, hipStream_t s) {
     if (powers_table(icoset_post.as<Fr>(), N, g.inverse(), n_inv, s)) return ZKG_ERROR;
     return ZKG_OK;
 }
-void NttDomain::release() { tw_fwd.release(); tw_inv.release(); coset_pre.release(); icoset_post.release(); scratch.release(); }
+void NttDomain::release() {
+    tw_fwd.release(); tw_inv.release(); coset_pre.release(); icoset_post.release(); scratch.release();
+    for (auto &kv : stream_scratch) kv.second.release();
+    stream_scratch.clear();
+}
+// transforms of one size on different streams must not share the inter-pass scratch vector
+Fr *NttDomain::scratch_for(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (first_stream_set && s == first_stream) return scratch.as<Fr>();
+    if (!first_stream_set) { first_stream_set = true; first_stream = s; return scratch.as<Fr>(); }
+    DevBuf &b = stream_scratch[s];
+    if (b.reserve(((size_t)1 << logn) * sizeof(Fr))) return nullptr;
+    return b.as<Fr>();
+}
 
 static std::mutex g_dom_mu;
 static std::map<unsigned, NttDomain *> g_domains;
@@ -152,14 +165,15 @@ void ntt_release_all() {
     g_domains.clear();
 }
 
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s) {
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch) {
     const unsigned n = d->logn;
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
     const size_t N = (size_t)1 << n;
     unsigned npass = (n + NTT_MAX_R - 1) / NTT_MAX_R;
     if (n <= (unsigned)NTT_TILE_LOG) npass = 1;
     unsigned base = n / npass, extra = n % npass;
-    Fr *tmp = d->scratch.as<Fr>();
+    Fr *tmp = scratch ? scratch : d->scratch_for(s);
+    if (!tmp) return ZKG_ERROR;
     unsigned s0 = 0;
     for (unsigned p = 0; p < npass; ++p) {
         unsigned R = base + (p < extra ? 1 : 0);

@@ -12,6 +12,9 @@
 // because they share the scalar vector [1 | w]; the prover randomness (r, s) is an explicit input.
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -30,8 +33,11 @@ struct zkg_crs {
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
     zk::DevBuf z, aA, aB, aC, flag;             // [1 | w] and the three evaluation vectors
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
+    zk::DevBuf ntt_scratch;                     // this CRS's own inter-pass vector (proofs on different CRSs may overlap)
+    hipStream_t stream = nullptr;               // mat-vec + NTT stream
+    zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;   // concurrent MSMs, one stream + workspace each
     float stage_ms[8] = {0};
-    hipEvent_t ev[9]; bool ev_ok = false;
+    hipEvent_t ev[16]; bool ev_ok = false;
     std::mutex mu;
 };
 
@@ -100,7 +106,7 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
     if (crs->n) ZK_HIP(hipMemcpyAsync(z + 1, witness, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
     ZK_HIP(hipMemsetAsync(crs->flag.p, 0, 4, s));
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[0], s);
+    if (crs->ev_ok) (void)hipEventRecord(crs->ev[0], s);                      // z = [1 | w] is resident from here on
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
@@ -111,11 +117,11 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
     // iFFT then cosetFFT, for each of aA, aB, aC: inverse transform with post table g^i/m, then a plain forward transform
     const Fr *fused = crs->coset_over_m.as<Fr>();
     for (Fr *v : {aA, aB, aC}) {
-        if (ntt_run_ex(crs->dom, v, true, nullptr, fused, nullptr, s)) return ZKG_ERROR;
-        if (ntt_run_ex(crs->dom, v, false, nullptr, nullptr, nullptr, s)) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, v, true, nullptr, fused, nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, v, false, nullptr, nullptr, nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;
     }
     hipLaunchKernelGGL(k_pointwise_h, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
-    if (ntt_run(crs->dom, aA, 1, 1, s)) return ZKG_ERROR;                    // icosetFFT -> coefficients_for_H[0..m)
+    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
     if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
@@ -154,11 +160,18 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
         ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
              crs->z.reserve((n + 1) * 32) == 0 && crs->aA.reserve(m * 32) == 0 && crs->aB.reserve(m * 32) == 0 && crs->aC.reserve(m * 32) == 0 &&
-             crs->flag.reserve(4) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+             crs->flag.reserve(4) == 0 && crs->ntt_scratch.reserve(m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+    }
+    if (ok) {
+        ok = hip_ok(hipStreamCreateWithFlags(&crs->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__);
+        crs->job_a = msm_job_create(nullptr, true); crs->job_b1 = msm_job_create(nullptr, true); crs->job_b2 = msm_job_create(nullptr, true);
+        crs->job_h = msm_job_create(nullptr, true); crs->job_l = msm_job_create(nullptr, true);
+        ok = ok && crs->job_a && crs->job_b1 && crs->job_b2 && crs->job_h && crs->job_l;
     }
     if (ok) {
         crs->ev_ok = true;
         for (auto &e : crs->ev) if (hipEventCreate(&e) != hipSuccess) crs->ev_ok = false;
+        if (!crs->ev_ok) { set_error("hipEventCreate failed"); ok = false; }
     }
     if (!ok) { zkg_crs_free(crs); return nullptr; }
     return crs;
@@ -167,8 +180,11 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
-                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag})
+                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag,
+                      &crs->ntt_scratch})
         b->release();
+    msm_job_destroy(crs->job_a); msm_job_destroy(crs->job_b1); msm_job_destroy(crs->job_b2); msm_job_destroy(crs->job_h); msm_job_destroy(crs->job_l);
+    if (crs->stream) (void)hipStreamDestroy(crs->stream);
     if (crs->ev_ok) for (auto &e : crs->ev) (void)hipEventDestroy(e);
     delete crs;
 }
@@ -178,7 +194,8 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
     if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
     uint32_t flag = 0;
-    if (compute_h(crs, witness, false, &flag, nullptr)) return ZKG_ERROR;
+    if (compute_h(crs, witness, false, &flag, crs->stream)) return ZKG_ERROR;
+    ZK_HIP(hipStreamSynchronize(crs->stream));
     ZK_HIP(hipMemcpy(h_out, crs->aA.p, crs->m * 32, hipMemcpyDeviceToHost));
     memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
     return ZKG_OK;
@@ -189,24 +206,45 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !witness)) { set_error("zkg_groth16_prove: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
-    hipStream_t s = nullptr;
+    hipStream_t s = crs->stream;
     const size_t n = crs->n, l = crs->l, m = crs->m;
+    auto t_wall0 = std::chrono::steady_clock::now();
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count()); };
     uint32_t flag = 0;
     if (compute_h(crs, witness, check_satisfied != 0, &flag, s)) return ZKG_ERROR;
+    lap("h pipeline enqueued");
+    // ---- multi-exponentiations, concurrently on their own streams.  Scalars are Montgomery Fr on device (converted on the fly).
+    //      A / B_g1 / B_g2 and L only need z (event 0); H needs the NTT pipeline (event 2).
+    const uint32_t *z = crs->z.as<uint32_t>();
+    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
+    struct Launch { MsmJob *job; const G1Affine *g1; const G2Affine *g2; const uint32_t *sc; size_t cnt; int wait_ev, ev0; };
+    const Launch launches[5] = {
+        {crs->job_b2, nullptr, crs->B_g2.as<G2Affine>(), z, n + 1, 0, 3},               // the G2 MSM is the long pole: first
+        {crs->job_a, crs->A_query.as<G1Affine>(), nullptr, z, n + 1, 0, 5},
+        {crs->job_b1, crs->B_g1.as<G1Affine>(), nullptr, z, n + 1, 0, 7},
+        {crs->job_l, crs->L_query.as<G1Affine>(), nullptr, z + 8 * (l + 1), n - l, 0, 9},
+        {crs->job_h, crs->H_query.as<G1Affine>(), nullptr, crs->aA.as<uint32_t>(), m - 1, 2, 11}};
+    for (const Launch &L : launches) {
+        hipStream_t js = msm_job_stream(L.job);
+        ZK_HIP(hipStreamWaitEvent(js, crs->ev[L.wait_ev], 0));
+        (void)hipEventRecord(crs->ev[L.ev0], js);
+        if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
+        (void)hipEventRecord(crs->ev[L.ev0 + 1], js);
+    }
+    lap("msm jobs enqueued");
     if (check_satisfied) {
         ZK_HIP(hipStreamSynchronize(s));
-        if (flag) { set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED; }
+        if (flag) {                                                          // drain the speculative MSMs, then refuse like snark.cpp:121-124
+            for (const Launch &L : launches) (void)hipStreamSynchronize(msm_job_stream(L.job));
+            set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
+        }
     }
-    // ---- multi-exponentiations.  Scalars are Montgomery Fr on device (converted on the fly).
-    const uint32_t *z = crs->z.as<uint32_t>();
-    const G1Affine *g1sets[2] = {crs->A_query.as<G1Affine>(), crs->B_g1.as<G1Affine>()};
-    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
-    if (msm_shared(g1sets, 2, crs->B_g2.as<G2Affine>(), z, n + 1, true, AB, &Bt2, s)) return ZKG_ERROR;
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[3], s);
-    if (msm_g1(crs->H_query.as<G1Affine>(), crs->aA.as<uint32_t>(), m - 1, true, &Ht, s)) return ZKG_ERROR;
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[4], s);
-    if (msm_g1(crs->L_query.as<G1Affine>(), z + 8 * (l + 1), n - l, true, &Lt, s)) return ZKG_ERROR;
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[5], s);
+    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr) ||
+        msm_job_finish(crs->job_h, &Ht, nullptr)) return ZKG_ERROR;
+    lap("4 G1 msm finished");
+    if (msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR;
+    lap("G2 msm finished");
     // ---- assembly (host; a handful of scalar multiplications)
     Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
     uint32_t rc[8], sc[8], rsc[8];
@@ -220,14 +258,14 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     size_t off = 0;
     off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
     *proof_len = off;
-    if (crs->ev_ok) {
-        (void)hipEventRecord(crs->ev[6], s);
-        if (hipEventSynchronize(crs->ev[6]) == hipSuccess) {
-            float t;
-            auto el = [&](int a, int b) { return hipEventElapsedTime(&t, crs->ev[a], crs->ev[b]) == hipSuccess ? t : -1.f; };
-            crs->stage_ms[0] = el(0, 1); crs->stage_ms[1] = el(1, 2); crs->stage_ms[2] = el(2, 3); crs->stage_ms[3] = 0; crs->stage_ms[4] = 0;
-            crs->stage_ms[5] = el(3, 4); crs->stage_ms[6] = el(4, 5); crs->stage_ms[7] = el(0, 6);
-        }
+    lap("assembled+serialised");
+    ZK_HIP(hipStreamSynchronize(s));
+    {
+        float t;
+        auto el = [&](int a, int b) { return hipEventElapsedTime(&t, crs->ev[a], crs->ev[b]) == hipSuccess ? t : -1.f; };
+        crs->stage_ms[0] = el(0, 1); crs->stage_ms[1] = el(1, 2); crs->stage_ms[2] = el(5, 6); crs->stage_ms[3] = el(7, 8); crs->stage_ms[4] = el(3, 4);
+        crs->stage_ms[5] = el(11, 12); crs->stage_ms[6] = el(9, 10);
+        crs->stage_ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count();
     }
     return ZKG_OK;
 }

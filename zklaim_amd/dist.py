@@ -21,7 +21,7 @@ def combine_partials_g1(partial_jac, group=None, device=None):
     """all-gather the per-rank normalised G1 partials (12 x u64) and add them; every rank returns the full result."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return np.asarray(partial_jac, dtype=np.uint64).copy()
     world = dist.get_world_size(group)
     mine = torch.from_numpy(np.ascontiguousarray(partial_jac, dtype=np.uint64).view(np.int64).copy())
