@@ -230,6 +230,19 @@ def main():
                      "note": "integer-VALU-bound kernel (about 10 Montgomery multiplications per 96 input bytes); see DESIGN.md"},
     }
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from the committed
+    # rocprofv3 --pmc passes over this same command (tools/pmc_collect.sh -> profiles/pmc_traffic.json), valid for N = 2^20.
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if args.logn == LOGN and os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            line["roofline"]["traffic"] = pmc.get("dominant_hbm_bytes_per_launch")
+            line["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x gather calibration + WRITE_SIZE, separate --pmc passes)"
+            line["roofline"]["algorithmic_bytes_per_launch"] = BYTES_PER_POINT * n
+            line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+        except Exception:
+            pass
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle's restatement of libff multi_exp<BDLO12> (kind "port": reference libsnark is an absent submodule),
         # timed on this host on the SAME 2^logn-point workload; also used to check the GPU result.
