@@ -5,8 +5,12 @@
 // There is no CPU fallback: every entry point fails with ZKG_ERROR when no HIP device is usable.
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 namespace zk {
 
@@ -47,6 +51,59 @@ float KernelTimer::drain(int *launches) {
     return n ? total / n : 0.f;
 }
 void KernelTimer::reset() { used = 0; }
+
+// ---- host thread pool -------------------------------------------------------------------------------------
+namespace {
+struct Run {                                   // one parallel_for: workers that wake late see next >= n and touch nothing else
+    std::function<void(int)> fn; int n = 0; std::atomic<int> next{0}, done{0};
+};
+struct Pool {
+    std::vector<std::thread> workers;
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::shared_ptr<Run> cur; uint64_t epoch = 0; bool stop = false;
+    std::mutex run_mu;                         // one parallel_for at a time
+    Pool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nw = (int)(hw > 16 ? 15 : (hw > 1 ? hw - 1 : 0));
+        for (int i = 0; i < nw; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void drain(Run &r) {
+        for (int i; (i = r.next.fetch_add(1)) < r.n;) {
+            r.fn(i);
+            if (r.done.fetch_add(1) + 1 == r.n) { std::lock_guard<std::mutex> lk(mu); cv_done.notify_all(); }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::shared_ptr<Run> r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || epoch != seen; });
+                if (stop) return;
+                seen = epoch; r = cur;
+            }
+            if (r) drain(*r);
+        }
+    }
+    void run(int count, const std::function<void(int)> &f) {
+        if (count <= 1 || workers.empty()) { for (int i = 0; i < count; ++i) f(i); return; }
+        std::lock_guard<std::mutex> rl(run_mu);
+        auto r = std::make_shared<Run>(); r->fn = f; r->n = count;
+        { std::lock_guard<std::mutex> lk(mu); cur = r; ++epoch; }
+        cv_work.notify_all();
+        drain(*r);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return r->done.load() == r->n; });
+    }
+};
+}  // namespace
+void host_parallel_for(int n, const std::function<void(int)> &fn) { static Pool pool; pool.run(n, fn); }
 
 // ---- ABI point encodings -----------------------------------------------------------------------
 static void put(uint64_t *out, const Fq &a) { memcpy(out, a.v, 32); }

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <functional>
 #include <map>
 #include <mutex>
 #include "curve.cuh"
@@ -32,6 +33,9 @@ struct KernelTimer {
     void reset();
 };
 extern KernelTimer g_dominant_timer;
+
+// small persistent host thread pool (the per-window tails of the MSMs are independent; see msm.hip host_combine)
+void host_parallel_for(int n, const std::function<void(int)> &fn);
 
 // ---------------- NTT (ntt.hip) ----------------
 struct NttDomain {

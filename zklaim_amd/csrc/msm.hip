@@ -162,9 +162,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_place(const uint32_t *digits, 
     }
 }
 
+// Heavy threshold, computed on the device from the real list lengths: a lane walks its bucket's list alone (~7 us per G1
+// addition at low occupancy), so the longest non-heavy list bounds the kernel's latency however little total work there is.
+// Lists are cut at 4x the true average length + 32 (the partly filled top window of uniform scalars averages ~2.7x the other
+// windows and stays on the lane-per-bucket path; a sparse bit-witness MSM gets a small threshold and a short tail).
+ZK_D uint32_t heavy_threshold_dev(const uint32_t *offsets, size_t total_buckets, uint32_t divisor) {
+    uint32_t entries = offsets[total_buckets];
+    uint32_t t = (uint32_t)(4 * (uint64_t)entries / total_buckets) + 32;
+    t = t > HEAVY_T_MAX ? HEAVY_T_MAX : t;
+    t /= divisor;
+    return t < 16 ? 16 : t;
+}
+
 // ---- 5. bucket order by descending length (classes 0..heavy_t, heavy_t+1 = heavy) ------------------------
-__global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, size_t total, uint32_t heavy_t, uint32_t *class_hist) {
+__global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, const uint32_t *offsets, size_t total, uint32_t *class_hist) {
     __shared__ uint32_t h[HEAVY_T_MAX + 2];
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
     const uint32_t t = threadIdx.x, nc = heavy_t + 2;
     for (uint32_t i = t; i < nc; i += 1024) h[i] = 0;
     __syncthreads();
@@ -173,13 +186,15 @@ __global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, siz
     __syncthreads();
     for (uint32_t i = t; i < nc; i += 1024) if (h[i]) atomicAdd(&class_hist[i], h[i]);
 }
-__global__ void k_class_scan(uint32_t *class_hist, uint32_t heavy_t) {       // in place: start position of every class, longest first
+__global__ void k_class_scan(uint32_t *class_hist, const uint32_t *offsets, size_t total) {       // in place: start position of every class, longest first
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
     uint32_t run = 0;
     for (int c = (int)heavy_t + 1; c >= 0; --c) { uint32_t v = class_hist[c]; class_hist[c] = run; run += v; }
 }
-__global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, size_t total, uint32_t heavy_t, uint32_t *class_cursor, uint32_t *order) {
+__global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, const uint32_t *offsets, size_t total, uint32_t *class_cursor, uint32_t *order) {
     __shared__ uint32_t h[HEAVY_T_MAX + 2];
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
     const uint32_t t = threadIdx.x, nc = heavy_t + 2;
     for (uint32_t i = t; i < nc; i += 1024) h[i] = 0;
     __syncthreads();
@@ -195,10 +210,11 @@ __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, si
 // ---- 6. bucket accumulation (dominant kernel) -------------------------------------------------------------
 template <class F>
 __global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
-                                                       size_t total_buckets, uint32_t heavy_t, XYZZ<F> *buckets,
+                                                       size_t total_buckets, XYZZ<F> *buckets,
                                                        HeavyItem *items, HeavyBucket *heavy, uint32_t *counters /* [0] items, [1] heavy buckets */) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= total_buckets) return;
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, total_buckets, sizeof(F) > sizeof(Fq) ? 3 : 1);   // a G2 addition costs ~3x a G1 addition
     const uint32_t gb = order[tid];
     uint32_t k = offsets[gb], end = offsets[gb + 1];
     if (end - k > heavy_t) {
@@ -346,16 +362,12 @@ struct MsmJob {
     std::mutex mu;
 };
 
-static uint32_t heavy_threshold(size_t n, MsmGeom g);
-
 template <class F>
 static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases, bool time_it) {
     const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B;
     hipStream_t s = job->stream;
-    uint32_t heavy_t = heavy_threshold(n, g);
-    if (sizeof(F) > sizeof(Fq)) heavy_t = heavy_t / 3 < 32 ? 32 : heavy_t / 3;      // a G2 addition costs ~3x a G1 addition: cut lists sooner
     size_t n_entries_max = n * g.W;
-    size_t max_heavy = n_entries_max / heavy_t + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;
+    size_t max_heavy = n_entries_max / 16 + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;     // worst case of the device-side threshold
     if (sl.heavy_items.reserve(max_items * sizeof(HeavyItem)) || sl.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
         sl.heavy_counters.reserve(8) || sl.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
     ZK_HIP(hipMemsetAsync(sl.heavy_counters.p, 0, 8, s));
@@ -364,7 +376,7 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
     XYZZ<F> *buckets = sl.buckets.as<XYZZ<F>>();
     if (time_it) g_dominant_timer.begin(s);
     hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
-                       d_bases, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, heavy_t, buckets,
+                       d_bases, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, buckets,
                        sl.heavy_items.as<HeavyItem>(), sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>());
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
@@ -384,9 +396,8 @@ template <class F>
 static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
     const MsmGeom g = job->g; const uint32_t cpw = job->cpw;
     const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(sl.host_red);
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = (int)g.W - 1; w >= 0; --w) {
-        for (uint32_t i = 0; i < g.c; ++i) acc = acc.dbl();
+    std::vector<XYZZ<F>> V(g.W);
+    host_parallel_for((int)g.W, [&](int w) {                                    // the windows are independent
         XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
         for (int ch = (int)cpw - 1; ch >= 0; --ch) {
             const XYZZ<F> &P = red[2 * ((size_t)w * cpw + ch)], &U = red[2 * ((size_t)w * cpw + ch) + 1];
@@ -394,22 +405,18 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
-        for (int i = 0; i < 11; ++i) weighted = weighted.dbl();            // * RED_CHUNK (2048)
-        acc.add(Usum); acc.add(weighted); acc.add(suffix);
+        if (!weighted.is_inf()) for (int i = 0; i < 11; ++i) weighted = weighted.dbl();   // * RED_CHUNK (2048)
+        Usum.add(weighted); Usum.add(suffix);
+        V[w] = Usum;
+    });
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = (int)g.W - 1; w >= 0; --w) {
+        if (!acc.is_inf()) for (uint32_t i = 0; i < g.c; ++i) acc = acc.dbl();
+        acc.add(V[w]);
     }
     return acc;
 }
 static_assert(RED_CHUNK == 2048 && RED_L == 8, "host combine assumes 2048-bucket chunks");
-
-// A lane walks its bucket's list alone, ~7 us per G1 addition at low occupancy, so the longest non-heavy list bounds the
-// kernel's latency however little total work there is: cut lists at a few times the average length (the partly filled
-// top window of uniform scalars averages ~2.7x the other windows and should stay on the lane-per-bucket path).
-static uint32_t heavy_threshold(size_t n, MsmGeom g) {
-    size_t avg = n / g.B, t = 4 * avg + 32;
-    if (t < 64) t = 64;
-    if (t > HEAVY_T_MAX) t = HEAVY_T_MAX;
-    return (uint32_t)t;
-}
 
 static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     const MsmGeom g = job->g; const size_t n = job->n;
@@ -417,7 +424,6 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     const size_t total = (size_t)g.W * g.B;
     uint32_t slice_len = (uint32_t)std::min<size_t>(65536, std::max<size_t>(4096, ((n + 15) / 16 + 1023) / 1024 * 1024));
     uint32_t S = (uint32_t)std::max<size_t>(1, (n + slice_len - 1) / slice_len);
-    const uint32_t heavy_t = heavy_threshold(n, g);
     size_t nblk = (total + 1024 * SCAN_ITEMS - 1) / (1024 * SCAN_ITEMS);
     if (nblk > 1024) { set_error("msm: too many buckets for the block scan"); return ZKG_ERROR; }
     if (job->digits.reserve(std::max<size_t>(1, n * g.W) * 4) || job->hist.reserve((size_t)g.W * S * g.B * 4) || job->counts.reserve(total * 4) ||
@@ -433,9 +439,9 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, offsets, sums, total);
     hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist, offsets, job->sorted.as<uint32_t>());
     ZK_HIP(hipMemsetAsync(chist, 0, (HEAVY_T_MAX + 2) * 4, s));
-    hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, total, heavy_t, chist);
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, chist, heavy_t);
-    hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, total, heavy_t, chist, job->order.as<uint32_t>());
+    hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, chist, offsets, total);
+    hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist, job->order.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) { set_error("msm sort launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
