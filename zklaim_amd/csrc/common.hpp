@@ -62,7 +62,7 @@ int ntt_configure();
 
 // ---------------- MSM (msm.hip) ----------------
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
-MsmJob *msm_job_create(hipStream_t s, bool own_stream);
+MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);
 hipStream_t msm_job_stream(MsmJob *j);
 void msm_job_destroy(MsmJob *j);
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);

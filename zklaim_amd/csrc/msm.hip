@@ -446,11 +446,13 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     return ZKG_OK;
 }
 
-MsmJob *msm_job_create(hipStream_t s, bool own_stream) {
+MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     MsmJob *j = new MsmJob();
     j->stream = s;
     if (own_stream) {
-        if (!hip_ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__)) { delete j; return nullptr; }
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (!hip_ok(hipStreamCreateWithPriority(&j->stream, hipStreamNonBlocking, high_priority ? prio_hi : prio_lo), "hipStreamCreate", __FILE__, __LINE__)) { delete j; return nullptr; }
         j->own_stream = true;
     }
     return j;

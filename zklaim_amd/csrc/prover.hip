@@ -33,11 +33,12 @@ struct zkg_crs {
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
     zk::DevBuf z, aA, aB, aC, flag;             // [1 | w] and the three evaluation vectors
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
-    zk::DevBuf ntt_scratch;                     // this CRS's own inter-pass vector (proofs on different CRSs may overlap)
-    hipStream_t stream = nullptr;               // mat-vec + NTT stream
+    zk::DevBuf ntt_scratch[3];                  // this CRS's own inter-pass vectors (one per concurrent transform chain)
+    hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
+    hipStream_t side[2] = {nullptr, nullptr};   // the B and C transform chains run beside the A chain
     zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;   // concurrent MSMs, one stream + workspace each
     float stage_ms[8] = {0};
-    hipEvent_t ev[16]; bool ev_ok = false;
+    hipEvent_t ev[20]; bool ev_ok = false;
     std::mutex mu;
 };
 
@@ -114,14 +115,19 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
                        z, crs->C, crs->l, m, aA, aB, aC, crs->flag.as<uint32_t>());
     if (want_flag) ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
-    // iFFT then cosetFFT, for each of aA, aB, aC: inverse transform with post table g^i/m, then a plain forward transform
+    // iFFT then cosetFFT for each of aA, aB, aC — three independent chains, run concurrently (a 2^18 transform fills half the
+    // chip): inverse transform with the fused post table g^i/m, then a plain forward transform
     const Fr *fused = crs->coset_over_m.as<Fr>();
-    for (Fr *v : {aA, aB, aC}) {
-        if (ntt_run_ex(crs->dom, v, true, nullptr, fused, nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;
-        if (ntt_run_ex(crs->dom, v, false, nullptr, nullptr, nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;
+    Fr *vecs[3] = {aA, aB, aC};
+    hipStream_t chain[3] = {s, crs->side[0], crs->side[1]};
+    for (int k = 0; k < 3; ++k) {
+        if (k) ZK_HIP(hipStreamWaitEvent(chain[k], crs->ev[1], 0));
+        if (ntt_run_ex(crs->dom, vecs[k], true, nullptr, fused, nullptr, chain[k], crs->ntt_scratch[k].as<Fr>())) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, vecs[k], false, nullptr, nullptr, nullptr, chain[k], crs->ntt_scratch[k].as<Fr>())) return ZKG_ERROR;
+        if (k) { (void)hipEventRecord(crs->ev[16 + k], chain[k]); ZK_HIP(hipStreamWaitEvent(s, crs->ev[16 + k], 0)); }
     }
     hipLaunchKernelGGL(k_pointwise_h, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
-    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
+    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch[0].as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
     if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
@@ -160,12 +166,16 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
         ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
              crs->z.reserve((n + 1) * 32) == 0 && crs->aA.reserve(m * 32) == 0 && crs->aB.reserve(m * 32) == 0 && crs->aC.reserve(m * 32) == 0 &&
-             crs->flag.reserve(4) == 0 && crs->ntt_scratch.reserve(m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+             crs->flag.reserve(4) == 0 && crs->ntt_scratch[0].reserve(m * 32) == 0 && crs->ntt_scratch[1].reserve(m * 32) == 0 && crs->ntt_scratch[2].reserve(m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
     }
     if (ok) {
-        ok = hip_ok(hipStreamCreateWithFlags(&crs->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__);
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
+        ok = hip_ok(hipStreamCreateWithPriority(&crs->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__) &&
+             hip_ok(hipStreamCreateWithPriority(&crs->side[0], hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__) &&
+             hip_ok(hipStreamCreateWithPriority(&crs->side[1], hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
         crs->job_a = msm_job_create(nullptr, true); crs->job_b1 = msm_job_create(nullptr, true); crs->job_b2 = msm_job_create(nullptr, true);
-        crs->job_h = msm_job_create(nullptr, true); crs->job_l = msm_job_create(nullptr, true);
+        crs->job_h = msm_job_create(nullptr, true, true); crs->job_l = msm_job_create(nullptr, true);
         ok = ok && crs->job_a && crs->job_b1 && crs->job_b2 && crs->job_h && crs->job_l;
     }
     if (ok) {
@@ -181,10 +191,11 @@ void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
                       &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag,
-                      &crs->ntt_scratch})
+                      &crs->ntt_scratch[0], &crs->ntt_scratch[1], &crs->ntt_scratch[2]})
         b->release();
     msm_job_destroy(crs->job_a); msm_job_destroy(crs->job_b1); msm_job_destroy(crs->job_b2); msm_job_destroy(crs->job_h); msm_job_destroy(crs->job_l);
     if (crs->stream) (void)hipStreamDestroy(crs->stream);
+    for (auto &st : crs->side) if (st) (void)hipStreamDestroy(st);
     if (crs->ev_ok) for (auto &e : crs->ev) (void)hipEventDestroy(e);
     delete crs;
 }
@@ -233,6 +244,15 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
         (void)hipEventRecord(crs->ev[L.ev0 + 1], js);
     }
     lap("msm jobs enqueued");
+    // host work that needs only the CRS and (r, s): overlaps the GPU
+    Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
+    uint32_t rc[8], sc[8], rsc[8];
+    canonical_limbs(r, rc); canonical_limbs(sv, sc); canonical_limbs(r * sv, rsc);
+    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
+    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
+    G1 r_delta1 = delta1.mul(rc, 8), s_delta1 = delta1.mul(sc, 8), rs_delta1 = delta1.mul(rsc, 8);
+    G2 s_delta2 = delta2.mul(sc, 8);
+    lap("crs-only host products");
     if (check_satisfied) {
         ZK_HIP(hipStreamSynchronize(s));
         if (flag) {                                                          // drain the speculative MSMs, then refuse like snark.cpp:121-124
@@ -245,16 +265,11 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     lap("4 G1 msm finished");
     if (msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR;
     lap("G2 msm finished");
-    // ---- assembly (host; a handful of scalar multiplications)
-    Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
-    uint32_t rc[8], sc[8], rsc[8];
-    canonical_limbs(r, rc); canonical_limbs(sv, sc); canonical_limbs(r * sv, rsc);
-    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
-    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
-    G1 gA = alpha; gA.add(AB[0]); gA.add(delta1.mul(rc, 8));                // A = alpha + sum a_i A_i(t) + r delta
-    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(delta1.mul(sc, 8));             // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
-    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(delta2.mul(sc, 8));               //                                        (G2)
-    G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(delta1.mul(rsc, 8).neg());
+    // ---- assembly (host).  The three products that involve only the CRS were computed while the GPU was busy (above).
+    G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
+    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
+    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
+    G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
     size_t off = 0;
     off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
     *proof_len = off;
