@@ -23,6 +23,7 @@ template <class F> struct Affine {
     ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
     static ZK_HD Affine inf() { return {F::zero(), F::zero()}; }
     ZK_HD Affine neg() const { return {x, y.neg()}; }
+    ZK_HD Affine normalized() const { return {x.normalized(), y.normalized()}; }       // canonical limbs, for stores to global memory
 };
 
 template <class F> struct XYZZ {
@@ -32,6 +33,7 @@ template <class F> struct XYZZ {
     static ZK_HD XYZZ from_affine(const Affine<F> &a) { return a.is_inf() ? inf() : XYZZ{a.x, a.y, F::one(), F::one()}; }
     ZK_HD bool is_inf() const { return zz.is_zero(); }
     ZK_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
+    ZK_HD XYZZ normalized() const { return {x.normalized(), y.normalized(), zz.normalized(), zzz.normalized()}; }
 
     // dbl-2008-s-1
     ZK_HD XYZZ dbl_inl() const {

@@ -9,6 +9,11 @@
 // physically pairs of 32-bit limbs and the multiplication below is written for that unit.
 // Host code (final window combine, proof assembly) uses the same struct with a 64-bit-limb
 // multiplication via unsigned __int128.
+//
+// Lazy reduction on the device: p < 2^254, so 4p < R = 2^256 and the Montgomery product of two values below 2p is again
+// below 2p WITHOUT the final conditional subtraction.  Device values therefore live in [0, 2p) ("lazy"); add/sub fold
+// with 2p; is_zero()/== know that 0 is represented by 0 or p; normalized() brings a value to [0, p) and is applied
+// wherever a value leaves the registers for global memory, so everything in HBM and everything the host sees is canonical.
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
@@ -24,6 +29,7 @@ struct FqParams {
     static constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr uint32_t TWO_P[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u, 0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
     static constexpr uint32_t INV32 = 0xe4866389u;
     static constexpr uint64_t INV64 = 0x87d20782e4866389ull;
 };
@@ -31,6 +37,7 @@ struct FrParams {
     static constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr uint32_t TWO_P[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
     static constexpr uint32_t INV32 = 0xefffffffu;
     static constexpr uint64_t INV64 = 0xc2e1f593efffffffull;
 };
@@ -42,8 +49,19 @@ struct alignas(16) Fp {
     static ZK_HD Fp zero() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
     static ZK_HD Fp one() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::ONE[i]; return r; }
     static ZK_HD Fp r2() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::R2[i]; return r; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+    ZK_HD bool is_zero() const {                     // lazy representation: 0 or p
+        uint32_t o = 0, q = 0;
+        for (int i = 0; i < 8; ++i) { o |= v[i]; q |= v[i] ^ PR::P[i]; }
+        return o == 0 || q == 0;
+    }
+    ZK_HD bool operator==(const Fp &b) const { return (*this - b).is_zero(); }
+    ZK_HD Fp normalized() const { return reduce_once(v); }
+#else
     ZK_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i]; return o == 0; }
     ZK_HD bool operator==(const Fp &b) const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i] ^ b.v[i]; return o == 0; }
+    ZK_HD Fp normalized() const { return *this; }
+#endif
     ZK_HD bool operator!=(const Fp &b) const { return !(*this == b); }
 
     // r = (t >= p) ? t - p : t      (t < 2p)
@@ -60,7 +78,17 @@ struct alignas(16) Fp {
         uint32_t t[8]; uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[j] + b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+        uint32_t s[8]; uint32_t br = 0;                 // lazy: a + b < 4p < 2^256; fold once with 2p
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)t[j] - PR::TWO_P[j] - br; s[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
+        Fp r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[j] = br ? t[j] : s[j];
+        return r;
+#else
         return reduce_once(t);               // p < 2^254: a + b < 2^255 never carries out
+#endif
     }
     friend ZK_HD Fp operator-(const Fp &a, const Fp &b) {
         uint32_t t[8]; uint32_t br = 0;
@@ -68,10 +96,17 @@ struct alignas(16) Fp {
         for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)a.v[j] - b.v[j] - br; t[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
         uint32_t mask = 0u - br; uint64_t c = 0; Fp r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { c += (uint64_t)t[j] + (PR::P[j] & mask); r.v[j] = (uint32_t)c; c >>= 32; }
+        for (int j = 0; j < 8; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+            c += (uint64_t)t[j] + (PR::TWO_P[j] & mask);
+#else
+            c += (uint64_t)t[j] + (PR::P[j] & mask);
+#endif
+            r.v[j] = (uint32_t)c; c >>= 32;
+        }
         return r;
     }
-    ZK_HD Fp neg() const { return is_zero() ? *this : (zero() - *this); }
+    ZK_HD Fp neg() const { return zero() - *this; }      // 0 - 0 = 0; otherwise p - a (host) / 2p - a (device, lazy)
     ZK_HD Fp dbl() const { return *this + *this; }
 
     // Montgomery product a*b*R^-1 mod p.
@@ -93,7 +128,10 @@ struct alignas(16) Fp {
                   "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
                 : ZK_MONT_MUL_CLOBBERS);
         }
-        return reduce_once(t);
+        Fp r;                                            // lazy: a, b < 2p  =>  t < 2p, no final subtraction
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[j] = t[j];
+        return r;
 #elif defined(__HIP_DEVICE_COMPILE__)
         // portable C++ form of the same product (kept for A/B checks: -DZK_MONT_CXX): CIOS over 32-bit limbs
 #else
@@ -121,7 +159,7 @@ struct alignas(16) Fp {
 #endif
     }
     ZK_HD Fp sqr() const { return (*this) * (*this); }
-    ZK_HD Fp from_mont() const { Fp o = zero(); o.v[0] = 1; return (*this) * o; }      // canonical value
+    ZK_HD Fp from_mont() const { Fp o = zero(); o.v[0] = 1; return ((*this) * o).normalized(); }      // canonical value
     ZK_HD Fp to_mont() const { return (*this) * r2(); }
     ZK_HD Fp &operator+=(const Fp &b) { *this = *this + b; return *this; }
     ZK_HD Fp &operator-=(const Fp &b) { *this = *this - b; return *this; }
@@ -165,6 +203,7 @@ struct Fq2 {
     }
     ZK_HD Fq2 sqr() const { Fq ab = c0 * c1; return {(c0 + c1) * (c0 - c1), ab + ab}; }
     ZK_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
+    ZK_HD Fq2 normalized() const { return {c0.normalized(), c1.normalized()}; }
     ZK_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
     ZK_HD Fq2 inverse() const { Fq d = (c0.sqr() + c1.sqr()).inverse(); return {c0 * d, (c1 * d).neg()}; }
     ZK_HD Fq2 &operator+=(const Fq2 &b) { *this = *this + b; return *this; }

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, co
             if (k >= end) break;
         }
     }
-    buckets[gb] = acc;
+    buckets[gb] = acc.normalized();
 }
 
 // one wavefront per heavy part: 64 lanes stride over <= HEAVY_S entries, then a 6-level LDS tree
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const Affine<F> *bases, con
             if (lane < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
             __syncthreads();
         }
-        if (lane == 0 && it < n_items) partials[it] = sh[t];
+        if (lane == 0 && it < n_items) partials[it] = sh[t].normalized();
         __syncthreads();
     }
 }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
             if (t < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
             __syncthreads();
         }
-        if (t == 0) buckets[h.gb] = sh[0];
+        if (t == 0) buckets[h.gb] = sh[0].normalized();
         __syncthreads();
     }
 }
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *bu
         XYZZ<F> E = sh[0];
         for (int i = 0; i < 3; ++i) E = E.dbl();                    // * RED_L (= 8)
         E.add(sh[RED_THREADS]);
-        out[2 * (size_t)blockIdx.x] = P;
-        out[2 * (size_t)blockIdx.x + 1] = E;
+        out[2 * (size_t)blockIdx.x] = P.normalized();
+        out[2 * (size_t)blockIdx.x + 1] = E.normalized();
     }
 }
 
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, cons
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int b = 0; b < 254; ++b)
         if ((k[b >> 5] >> (b & 31)) & 1u) acc.madd(table[b]);
-    out[i] = acc.to_affine();
+    out[i] = acc.to_affine().normalized();
 }
 
 template <class F>

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
         Fr v = lds_ld(mid, c);
         if (A.post) v = v * A.post[idx];
         else if (A.has_post_scalar) v = v * A.post_scalar;
-        A.dst[idx] = v;
+        A.dst[idx] = v.normalized();
     }
 }
 
@@ -93,12 +93,12 @@ __global__ void k_powers(Fr *out, size_t n, Fr base, Fr scale) {
     size_t i0 = t * 64;
     if (i0 >= n) return;
     Fr cur = scale * base.pow_u64(i0);
-    for (size_t i = i0; i < i0 + 64 && i < n; ++i) { out[i] = cur; cur = cur * base; }
+    for (size_t i = i0; i < i0 + 64 && i < n; ++i) { out[i] = cur.normalized(); cur = cur * base; }
 }
 
 __global__ void k_scale(Fr *a, size_t n, Fr s) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = a[i] * s;
+    if (i < n) a[i] = (a[i] * s).normalized();
 }
 
 int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s) {

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const u
     } else if (i <= (size_t)C + l) {
         a = z[i - C];
     }
-    aA[i] = a; aB[i] = b; aC[i] = c;
+    aA[i] = a.normalized(); aB[i] = b.normalized(); aC[i] = c.normalized();
 }
 
 __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one(); }
@@ -70,7 +70,7 @@ __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0]
 __global__ __launch_bounds__(256) void k_pointwise_h(Fr *aA, const Fr *aB, const Fr *aC, size_t m, Fr zinv) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    aA[i] = (aA[i] * aB[i] - aC[i]) * zinv;
+    aA[i] = ((aA[i] * aB[i] - aC[i]) * zinv).normalized();
 }
 
 static int upload(DevBuf &d, const void *src, size_t bytes) {
