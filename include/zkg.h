@@ -121,6 +121,11 @@ int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t
 /* ---- CRS residency: parse once, keep on device (removes the per-call pk re-parse of
  *      libsnark_wrapper.cpp:230 and the by-value pk copy of snark.cpp:107-109).        */
 zkg_crs *zkg_crs_upload(const zkg_pk *pk);
+/* Same, from the byte blob zklaim keeps in ctx->pk (written by libsnark_export_pk, libsnark_wrapper.cpp:146-157, i.e.
+ * operator<<(r1cs_gg_ppzksnark_proving_key) under libsnark's default flags: binary, Montgomery, compressed points).
+ * Replaces libsnark_import_pk (libsnark_wrapper.cpp:160-168); the ~4n+m point decompressions (one square root each) run
+ * on the GPU.  Only basic_radix2 domains (|H_query| + 1 a power of two).                                             */
+zkg_crs *zkg_crs_upload_blob(const void *pk_blob, size_t len);
 void     zkg_crs_free(zkg_crs *crs);
 
 /* ---- Groth16 prove: r1cs_gg_ppzksnark_prover (snark.cpp:126) with the prover

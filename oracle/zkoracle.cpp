@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include <vector>
 #include <algorithm>
 #ifdef _OPENMP
@@ -642,6 +643,37 @@ int zko_groth16_setup(const zkg_r1cs *cs, const u64 *td, u64 *alpha_g1, u64 *bet
     if (Ct_out) memcpy(Ct_out, Ct.data(), (n + 1) * 32);
     if (Zt_out) memcpy(Zt_out, Zt.v, 32);
     return 0;
+}
+
+/* Writer of the libsnark proving-key byte format (operator<< of r1cs_gg_ppzksnark_proving_key under BINARY_OUTPUT,
+ * MONTGOMERY_OUTPUT and point compression; exported by libsnark_export_pk, libsnark_wrapper.cpp:146-157) from flat arrays.
+ * Returns the number of bytes needed; writes only if cap is large enough.  Test infrastructure for zkg_crs_upload_blob. */
+size_t zko_pk_write_blob(const zkg_pk *pk, uint8_t *out, size_t cap) {
+    std::vector<uint8_t> buf;
+    auto dec = [&](size_t v) { char t[32]; int n = snprintf(t, sizeof t, "%zu\n", v); buf.insert(buf.end(), t, t + n); };
+    auto g1 = [&](const u64 *p) { uint8_t t[34]; ser_g1(t, G1::from_affine(load_g1(p))); buf.insert(buf.end(), t, t + 34); };
+    auto g2 = [&](const u64 *p) { uint8_t t[66]; ser_g2(t, G2::from_affine(load_g2(p))); buf.insert(buf.end(), t, t + 66); };
+    const zkg_r1cs &cs = pk->cs;
+    size_t n = cs.num_variables, l = cs.num_inputs, m = (size_t)1 << pk->log_m;
+    g1(pk->alpha_g1); g1(pk->beta_g1); g2(pk->beta_g2); g1(pk->delta_g1); g2(pk->delta_g2);
+    dec(n + 1); for (size_t i = 0; i <= n; ++i) g1(pk->A_query + 8 * i);
+    std::vector<size_t> idx;
+    for (size_t i = 0; i <= n; ++i) if (!all_zero(pk->B_g2 + 16 * i, 16) || !all_zero(pk->B_g1 + 8 * i, 8)) idx.push_back(i);
+    dec(n + 1); dec(idx.size()); for (size_t i : idx) dec(i);
+    dec(idx.size()); for (size_t i : idx) { g2(pk->B_g2 + 16 * i); g1(pk->B_g1 + 8 * i); }
+    dec(m - 1); for (size_t i = 0; i + 1 < m; ++i) g1(pk->H_query + 8 * i);
+    dec(n - l); for (size_t i = 0; i < n - l; ++i) g1(pk->L_query + 8 * i);
+    dec(l); dec(n - l); dec(cs.num_constraints);
+    for (u32 c = 0; c < cs.num_constraints; ++c) {
+        const u32 *rp[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr}, *col[3] = {cs.a_col, cs.b_col, cs.c_col};
+        const u64 *val[3] = {cs.a_val, cs.b_val, cs.c_val};
+        for (int k = 0; k < 3; ++k) {
+            dec(rp[k][c + 1] - rp[k][c]);
+            for (u32 t = rp[k][c]; t < rp[k][c + 1]; ++t) { dec(col[k][t]); const uint8_t *b = (const uint8_t *)(val[k] + 4 * (size_t)t); buf.insert(buf.end(), b, b + 32); }
+        }
+    }
+    if (out && cap >= buf.size()) memcpy(out, buf.data(), buf.size());
+    return buf.size();
 }
 
 int zko_num_threads(void) {

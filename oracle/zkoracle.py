@@ -188,5 +188,14 @@ def groth16_prove(pk, w, r, s, check_satisfied=True, chunks=1):
     return rc, bytes(out[:ln.value])
 
 
+def pk_write_blob(pk):
+    lib().zko_pk_write_blob.restype = C.c_size_t
+    need = lib().zko_pk_write_blob(C.byref(pk), None, C.c_size_t(0))
+    out = np.zeros(need, np.uint8)
+    got = lib().zko_pk_write_blob(C.byref(pk), _p(out), C.c_size_t(need))
+    assert got == need
+    return out.tobytes()
+
+
 def num_threads():
     return lib().zko_num_threads()

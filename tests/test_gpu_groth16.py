@@ -52,3 +52,44 @@ def test_prove_zklaim_shaped_vs_oracle(zkg, oracle, log_m):
     assert rc == 0 and proof == proof_o
     print("stage ms", crs.stage_ms())
     crs.free()
+
+
+@pytest.mark.parametrize("case", CASES[1:3], ids=[c["tag"] for c in CASES[1:3]])
+def test_prove_from_pk_blob(zkg, oracle, case):
+    """ctx->pk style byte blob (libsnark operator<< format, compressed points) -> GPU decompression -> same proof bytes."""
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    ocs = oracle.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
+    blob = oracle.pk_write_blob(oracle.make_pk(ocs, pts))
+    crs = zkg.Crs(blob=blob, m=case["m"])
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    crs.free()
+    # corrupt one x coordinate: the point falls off the curve (or the proof changes); truncated blobs are refused
+    bad = bytearray(blob); bad[40] ^= 0x55
+    try:
+        crs2 = zkg.Crs(blob=bytes(bad), m=case["m"])
+        rc2, proof2 = crs2.prove(w, r, s)
+        assert proof2 != proof
+        crs2.free()
+    except zkg.ZkgError:
+        pass
+    with pytest.raises(zkg.ZkgError):
+        zkg.Crs(blob=blob[: len(blob) // 2], m=case["m"])
+
+
+def test_pk_blob_zklaim_shaped(zkg, oracle):
+    from zklaim_amd import synth
+    log_m = 12
+    n, l, A, B, C, w = synth.zklaim_shaped(log_m, num_inputs=5, seed=3)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x44))
+    opk = oracle.make_pk(ocs, crs_arrays)
+    rs = random_fr_canonical(2, 0x45)
+    rc_o, proof_o = oracle.groth16_prove(opk, w, rs[0], rs[1])
+    blob = oracle.pk_write_blob(opk)
+    crs = zkg.Crs(blob=blob, m=1 << log_m)
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc_o == 0 and rc == 0 and proof == proof_o
+    crs.free()

@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libzkg.so")
 DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
-    "zkg_crs_upload", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
+    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms",
 ]
 
@@ -48,6 +48,8 @@ def lib():
         _lib.zkg_timing_dominant_ms.restype = C.c_float
         _lib.zkg_crs_upload.restype = C.c_void_p
         _lib.zkg_crs_upload.argtypes = [C.c_void_p]
+        _lib.zkg_crs_upload_blob.restype = C.c_void_p
+        _lib.zkg_crs_upload_blob.argtypes = [C.c_void_p, C.c_size_t]
         _lib.zkg_crs_free.argtypes = [C.c_void_p]
     return _lib
 
@@ -185,11 +187,17 @@ def make_pk(cs, arrays, log_m, keep):
 class Crs:
     """Device-resident proving key (zkg_crs_upload): parsed once, reused for every proof."""
 
-    def __init__(self, pk):
-        self._h = lib().zkg_crs_upload(C.byref(pk))
+    def __init__(self, pk=None, blob=None, m=None):
+        """from a zkg_pk struct of flat arrays, or from a libsnark pk byte blob (ctx->pk)"""
+        if blob is not None:
+            buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+            self._h = lib().zkg_crs_upload_blob(C.cast(buf, C.c_void_p), C.c_size_t(len(blob)))
+            self.m = m
+        else:
+            self._h = lib().zkg_crs_upload(C.byref(pk))
+            self.m = 1 << pk.log_m
         if not self._h:
             raise ZkgError("zkg_crs_upload failed: " + lib().zkg_last_error().decode())
-        self.m = 1 << pk.log_m
 
     def prove(self, witness, r, s, check_satisfied=True):
         """-> (rc, proof bytes); rc == 1 reproduces libsnark_prove's 'system not satisfied' return."""
