@@ -146,6 +146,19 @@ int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_o
  * [6] MSM L, [7] wall-clock total incl. host assembly                                  */
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
 
+/* ---- zklaim's credential circuit on the host: replaces protoboard + zklaim_gadget construction,
+ *      generate_r1cs_constraints and generate_r1cs_witness (snark.cpp:113-118, zklaim_gadget.cpp:153-784) and
+ *      zklaim_input_map (zklaim_gadget.cpp:115-150).  `ctx` is zklaim's own zklaim_ctx (include/zklaim_abi.h).           */
+struct zklaim_ctx;
+typedef struct zkg_circuit zkg_circuit;
+zkg_circuit *zkg_zklaim_circuit_new(const struct zklaim_ctx *ctx, int with_witness);
+void zkg_circuit_free(zkg_circuit *c);
+int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out);        /* pointers stay valid until zkg_circuit_free            */
+const uint64_t *zkg_circuit_witness(const zkg_circuit *c);        /* num_variables x 4 limbs (NULL without witness)        */
+int zkg_circuit_is_satisfied(const zkg_circuit *c);               /* pb.is_satisfied() (snark.cpp:121)                     */
+long zkg_circuit_first_unsatisfied(const zkg_circuit *c);         /* index of the first violated constraint, -1 if none    */
+size_t zkg_zklaim_input_map(const struct zklaim_ctx *ctx, uint64_t *out, size_t cap_elems);   /* returns the element count */
+
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
  * average device ms per launch of the dominant kernel over the calls since the last reset */
 void  zkg_timing_reset(void);

@@ -93,3 +93,32 @@ def test_pk_blob_zklaim_shaped(zkg, oracle):
     rc, proof = crs.prove(w, rs[0], rs[1])
     assert rc_o == 0 and rc == 0 and proof == proof_o
     crs.free()
+
+
+def test_prove_real_zklaim_circuit(zkg, oracle):
+    """One-payload zklaim credential (the reference's main.c / can_proof shape): circuit + witness from the host layer,
+    CRS from the oracle's known-trapdoor generator, proof bytes GPU == oracle; an unsatisfied credential returns 1."""
+    keep = []
+    pl = dict(attrs=[1994, 7, 42, 0, 5], refs=[2000, 7, 41, 0, 0], ops=["less", "eq", "greater", "noop", "noop"], salt=0xABCDEF)
+    ctx = zkg.make_ctx([pl], keep)
+    ck = zkg.ZklaimCircuit(ctx)
+    assert ck.is_satisfied()
+    n, l = ck.r1cs.num_variables, ck.r1cs.num_inputs
+    A, B, C = ck.csr(); w = ck.witness()
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x77))
+    log_m = crs_arrays["m"].bit_length() - 1
+    assert log_m == 15
+    opk = oracle.make_pk(ocs, crs_arrays)
+    rs = random_fr_canonical(2, 0x78)
+    rc_o, proof_o = oracle.groth16_prove(opk, w, rs[0], rs[1])
+    cs = zkg.make_r1cs(n, l, A, B, C, keep)
+    crs = zkg.Crs(zkg.make_pk(cs, crs_arrays, log_m, keep))
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc_o == 0 and rc == 0 and proof == proof_o
+    print("zklaim k=1 prove stage ms", crs.stage_ms())
+    bad = dict(pl); bad["ops"] = ["greater", "eq", "greater", "noop", "noop"]           # 1994 > 2000 is false
+    wbad = zkg.ZklaimCircuit(zkg.make_ctx([bad], keep)).witness()
+    rc, _ = crs.prove(wbad, rs[0], rs[1])
+    assert rc == 1
+    crs.free()

@@ -1,0 +1,79 @@
+"""CPU suite: zklaim's credential circuit rebuilt on the host (zklaim_amd/csrc/zklaim_circuit.hip) — the R1CS + witness
+that the reference builds with zklaim_gadget (zklaim_gadget.cpp:153-784).  Checked against SHA-256 from hashlib, the oracle's
+R1CS evaluator and the truth table of the comparison operators.  No GPU needed: this layer is host code."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+import zklaim_amd as zkg
+from util import R, ints
+
+ATTRS = [1994, 7, 42, 0, 2 ** 64 - 1]
+
+
+def payload(ops, refs, attrs=ATTRS, salt=0x1122334455667788, **kw):
+    return dict(attrs=attrs, refs=refs, ops=ops, salt=salt, **kw)
+
+
+def test_single_payload_satisfied_and_shapes(oracle):
+    keep = []
+    ctx = zkg.make_ctx([payload(["less", "eq", "greater", "noop", "greater_or_eq"], [2000, 7, 41, 5, 2 ** 64 - 1])], keep)
+    ck = zkg.ZklaimCircuit(ctx)
+    assert ck.is_satisfied(), ck.first_unsatisfied()
+    n, l, C = ck.r1cs.num_variables, ck.r1cs.num_inputs, ck.r1cs.num_constraints
+    assert l == 6                                           # ceil(1280 / 253), zklaim_gadget.cpp:357-362
+    assert 24576 < C + l + 1 <= 32768, C                     # k = 1 lands on the 2^15 radix-2 domain like the reference's circuit
+    # the oracle's evaluator agrees that the exported CSR + witness is a satisfied system
+    A, B, Cm = ck.csr(); w = ck.witness()
+    ocs = oracle.make_r1cs(n, l, A, B, Cm, keep)
+    assert oracle.r1cs_is_satisfied(ocs, w)
+    # public input == zklaim_input_map(ctx) (what the verifier recomputes, zklaim_gadget.cpp:115-150)
+    assert np.array_equal(zkg.zklaim_input_map(ctx), w[:l])
+    # structure does not depend on the witness: the setup-time circuit has the same shape
+    ck0 = zkg.ZklaimCircuit(ctx, with_witness=False)
+    assert (ck0.r1cs.num_variables, ck0.r1cs.num_inputs, ck0.r1cs.num_constraints) == (n, l, C)
+    for (r0, c0, v0), (r1, c1, v1) in zip(ck0.csr(), ck.csr()):
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1) and np.array_equal(v0, v1)
+    print("zklaim k=1: variables", n, "constraints", C)
+
+
+def test_sha256_gadget_matches_hashlib():
+    """the hash bits are public inputs; a wrong digest (any single bit) must violate the system"""
+    keep = []
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        attrs = [int(x) for x in rng.integers(0, 2 ** 63, 5)]
+        salt = int(rng.integers(0, 2 ** 63))
+        good = zkg.make_ctx([payload(["noop"] * 5, [0] * 5, attrs=attrs, salt=salt)], keep)
+        assert zkg.ZklaimCircuit(good).is_satisfied()
+        pre = struct.pack("<5QQ", *attrs, salt)
+        h = bytearray(hashlib.sha256(pre).digest())
+        h[int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        bad = zkg.make_ctx([payload(["noop"] * 5, [0] * 5, attrs=attrs, salt=salt, hash=bytes(h))], keep)
+        assert not zkg.ZklaimCircuit(bad).is_satisfied()
+
+
+@pytest.mark.parametrize("op,fn", [("less", lambda a, b: a < b), ("less_or_eq", lambda a, b: a <= b), ("eq", lambda a, b: a == b),
+                                   ("greater_or_eq", lambda a, b: a >= b), ("greater", lambda a, b: a > b), ("not_eq", lambda a, b: a != b),
+                                   ("noop", lambda a, b: True)])
+def test_comparison_truth_table(op, fn):
+    keep = []
+    for a, b in [(5, 9), (9, 5), (7, 7), (0, 0), (0, 2 ** 64 - 1), (2 ** 64 - 1, 0), (2 ** 64 - 1, 2 ** 64 - 1), (2 ** 63, 2 ** 63 - 1)]:
+        ctx = zkg.make_ctx([payload([op, "noop", "noop", "noop", "noop"], [b, 0, 0, 0, 0], attrs=[a, 1, 2, 3, 4])], keep)
+        assert zkg.ZklaimCircuit(ctx).is_satisfied() == fn(a, b), (op, a, b)
+
+
+def test_payload_counts(oracle):
+    """k = 0 (tests/zklaim.cpp:341-353 can_handle_no_payload), 2 and 3 payloads (can_handle_two/three_payloads)"""
+    keep = []
+    ck = zkg.ZklaimCircuit(zkg.make_ctx([], keep))
+    assert ck.is_satisfied() and ck.r1cs.num_inputs == 0 and ck.r1cs.num_constraints == 1
+    pls = [payload(["less", "noop", "noop", "noop", "noop"], [3000, 0, 0, 0, 0], salt=s) for s in (1, 2, 3)]
+    for k in (2, 3):
+        ctx = zkg.make_ctx(pls[:k], keep)
+        ck = zkg.ZklaimCircuit(ctx)
+        assert ck.is_satisfied()
+        assert ck.r1cs.num_inputs == -(-1280 * k // 253)
+        assert np.array_equal(zkg.zklaim_input_map(ctx), ck.witness()[: ck.r1cs.num_inputs])

@@ -16,7 +16,8 @@ DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
-    "zkg_timing_dominant_ms",
+    "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
+    "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map",
 ]
 
 
@@ -226,3 +227,117 @@ class Crs:
             self.free()
         except Exception:
             pass
+
+
+# ---- zklaim front-end structures (include/zklaim_abi.h) and the credential circuit --------------------------------
+class ZklaimPayload(C.Structure):
+    _fields_ = [("data_ref", C.c_uint64 * 5), ("data_op", C.c_int * 5), ("salt", C.c_uint64), ("hash", C.c_ubyte * 32), ("priv", C.c_uint8),
+                ("pre", C.c_ubyte * 48)]
+
+
+class ZklaimWrapPayload(C.Structure):
+    pass
+
+
+ZklaimWrapPayload._fields_ = [("next", C.POINTER(ZklaimWrapPayload)), ("pl", ZklaimPayload)]
+
+
+class ZklaimCtx(C.Structure):
+    _fields_ = [("num_of_payloads", C.c_size_t), ("pl_ctx_head", C.POINTER(ZklaimWrapPayload)), ("pk_size", C.c_size_t), ("pk", C.c_void_p),
+                ("vk_size", C.c_size_t), ("vk", C.c_void_p), ("proof_size", C.c_size_t), ("proof", C.c_void_p), ("pub_key", C.c_ubyte * 32),
+                ("signature", C.c_ubyte * 64)]
+
+
+OPS = dict(less=1, less_or_eq=3, eq=2, greater_or_eq=10, greater=8, not_eq=9, noop=99)
+
+
+def make_ctx(payloads, keep):
+    """payloads: list of dicts(attrs=[5 u64], refs=[5 u64], ops=[5 names], salt=u64, hash=bytes|None).  hash None -> SHA-256(pre),
+    as zklaim_hash_pl computes it (zklaim.c:114-121)."""
+    import hashlib
+    import struct
+    ctx = ZklaimCtx()
+    ctx.num_of_payloads = len(payloads)
+    nodes = []
+    for p in payloads:
+        node = ZklaimWrapPayload()
+        pre = struct.pack("<5QQ", *p["attrs"], p.get("salt", 0))
+        node.pl.pre[:] = list(pre)
+        for j in range(5):
+            node.pl.data_ref[j] = p["refs"][j]
+            node.pl.data_op[j] = OPS[p["ops"][j]]
+        node.pl.salt = p.get("salt", 0)
+        h = p.get("hash") or hashlib.sha256(pre).digest()
+        node.pl.hash[:] = list(h)
+        nodes.append(node)
+    for a, b in zip(nodes, nodes[1:]):
+        a.next = C.pointer(b)
+    if nodes:
+        ctx.pl_ctx_head = C.pointer(nodes[0])
+    keep.append(nodes)
+    return ctx
+
+
+class ZklaimCircuit:
+    """R1CS (+ witness) of zklaim_gadget for a zklaim_ctx, built on the host by libzkg.so"""
+
+    def __init__(self, ctx, with_witness=True):
+        L = lib()
+        L.zkg_zklaim_circuit_new.restype = C.c_void_p
+        L.zkg_zklaim_circuit_new.argtypes = [C.c_void_p, C.c_int]
+        L.zkg_circuit_witness.restype = C.c_void_p
+        L.zkg_circuit_first_unsatisfied.restype = C.c_long
+        for f in (L.zkg_circuit_free, L.zkg_circuit_witness, L.zkg_circuit_is_satisfied, L.zkg_circuit_first_unsatisfied):
+            f.argtypes = [C.c_void_p]
+        L.zkg_circuit_r1cs.argtypes = [C.c_void_p, C.c_void_p]
+        self._h = L.zkg_zklaim_circuit_new(C.cast(C.pointer(ctx), C.c_void_p), int(with_witness))
+        if not self._h:
+            raise ZkgError("zkg_zklaim_circuit_new failed: " + L.zkg_last_error().decode())
+        self.r1cs = R1CS()
+        _check(L.zkg_circuit_r1cs(self._h, C.byref(self.r1cs)), "zkg_circuit_r1cs")
+        self.with_witness = with_witness
+
+    def witness(self):
+        p = lib().zkg_circuit_witness(self._h)
+        if not p:
+            return None
+        n = self.r1cs.num_variables
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4)).copy()
+
+    def is_satisfied(self):
+        return bool(lib().zkg_circuit_is_satisfied(self._h))
+
+    def first_unsatisfied(self):
+        return int(lib().zkg_circuit_first_unsatisfied(self._h))
+
+    def csr(self):
+        """numpy copies of the three CSR matrices: (rowptr, col, val) x 3"""
+        out = []
+        C_ = self.r1cs.num_constraints
+        for m in "abc":
+            rp = np.ctypeslib.as_array(C.cast(getattr(self.r1cs, m + "_rowptr"), C.POINTER(C.c_uint32)), shape=(C_ + 1,)).copy()
+            nnz = int(rp[-1])
+            col = np.ctypeslib.as_array(C.cast(getattr(self.r1cs, m + "_col"), C.POINTER(C.c_uint32)), shape=(max(nnz, 1),))[:nnz].copy()
+            val = np.ctypeslib.as_array(C.cast(getattr(self.r1cs, m + "_val"), C.POINTER(C.c_uint64)), shape=(max(nnz, 1), 4))[:nnz].copy()
+            out.append((rp, col, val))
+        return out
+
+    def free(self):
+        if self._h:
+            lib().zkg_circuit_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def zklaim_input_map(ctx):
+    L = lib()
+    L.zkg_zklaim_input_map.restype = C.c_size_t
+    L.zkg_zklaim_input_map.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    n = L.zkg_zklaim_input_map(C.cast(C.pointer(ctx), C.c_void_p), None, 0)
+    out = np.zeros((n, 4), np.uint64)
+    L.zkg_zklaim_input_map(C.cast(C.pointer(ctx), C.c_void_p), _p(out), n)
+    return out

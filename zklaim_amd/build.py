@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libzkg.so")
-SOURCES = ["ntt.hip", "msm.hip", "prover.hip", "codec.hip", "capi.hip"]
+SOURCES = ["ntt.hip", "msm.hip", "prover.hip", "codec.hip", "zklaim_circuit.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -14,7 +14,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "zkg.h")]
+    deps = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(HERE, "..", "include", f) for f in ("zkg.h", "zklaim_abi.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,66 @@
+// r1cs_builder.hpp — host-side constraint-system builder (what zklaim uses libsnark's protoboard / pb_variable /
+// linear_combination / r1cs_constraint for: /root/reference/zklaim/snark.cpp:113-118, zklaim_gadget.cpp:18-20).
+// Variable 0 is the constant ONE; variables 1..num_inputs are the primary input; the rest is the auxiliary input.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+#include "../fp.cuh"
+
+namespace zk { namespace circuit {
+
+typedef uint32_t Var;                    // 0 == ONE
+
+struct LC {                              // sparse linear combination sum coeff_i * x_i
+    std::vector<std::pair<Var, Fr>> t;
+    LC() {}
+    LC(Var v) { t.push_back({v, Fr::one()}); }
+    static LC constant(const Fr &c) { LC r; if (!c.is_zero()) r.t.push_back({0, c}); return r; }
+    static LC constant(uint64_t c) { return constant(Fr::from_u64(c)); }
+    LC &add(Var v, const Fr &c) { if (!c.is_zero()) t.push_back({v, c}); return *this; }
+    LC operator+(const LC &o) const { LC r = *this; r.t.insert(r.t.end(), o.t.begin(), o.t.end()); return r; }
+    LC operator-(const LC &o) const { LC r = *this; for (auto &e : o.t) r.t.push_back({e.first, e.second.neg()}); return r; }
+    LC operator*(const Fr &c) const { LC r; if (c.is_zero()) return r; for (auto &e : t) r.t.push_back({e.first, e.second * c}); return r; }
+    LC operator*(uint64_t c) const { return (*this) * Fr::from_u64(c); }
+    bool is_constant() const { for (auto &e : t) if (e.first != 0) return false; return true; }
+};
+
+struct Constraint { LC a, b, c; };
+
+struct Builder {
+    std::vector<Fr> val;                 // val[0] == 1
+    std::vector<Constraint> cons;
+    uint32_t num_inputs = 0;
+    Builder() { val.push_back(Fr::one()); }
+    Var alloc() { val.push_back(Fr::zero()); return (Var)(val.size() - 1); }
+    std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
+    void set_input_sizes(uint32_t n) { num_inputs = n; }
+    uint32_t num_variables() const { return (uint32_t)val.size() - 1; }
+    void enforce(const LC &a, const LC &b, const LC &c) { cons.push_back({a, b, c}); }
+    void enforce_boolean(Var v) { enforce(LC(v), LC::constant(1) - LC(v), LC()); }          // v (1 - v) = 0
+    Fr eval(const LC &l) const { Fr s = Fr::zero(); for (auto &e : l.t) s += e.second * val[e.first]; return s; }
+    bool is_satisfied() const { for (auto &c : cons) if (eval(c.a) * eval(c.b) != eval(c.c)) return false; return true; }
+    size_t first_unsatisfied() const { for (size_t i = 0; i < cons.size(); ++i) if (eval(cons[i].a) * eval(cons[i].b) != eval(cons[i].c)) return i; return (size_t)-1; }
+
+    // CSR export (terms on the same variable merged, zero coefficients dropped): the zkg_r1cs layout
+    struct Csr { std::vector<uint32_t> rowptr, col; std::vector<uint64_t> val; };
+    static void push_row(Csr &m, const LC &l) {
+        std::vector<std::pair<Var, Fr>> s = l.t;
+        std::stable_sort(s.begin(), s.end(), [](const std::pair<Var, Fr> &x, const std::pair<Var, Fr> &y) { return x.first < y.first; });
+        for (size_t i = 0; i < s.size();) {
+            Fr acc = Fr::zero(); size_t j = i;
+            for (; j < s.size() && s[j].first == s[i].first; ++j) acc += s[j].second;
+            if (!acc.is_zero()) { m.col.push_back(s[i].first); uint64_t l4[4]; memcpy(l4, acc.v, 32); m.val.insert(m.val.end(), l4, l4 + 4); }
+            i = j;
+        }
+        m.rowptr.push_back((uint32_t)m.col.size());
+    }
+    void export_csr(Csr &A, Csr &B, Csr &C) const {
+        for (Csr *m : {&A, &B, &C}) { m->rowptr.assign(1, 0); m->col.clear(); m->val.clear(); }
+        for (auto &c : cons) { push_row(A, c.a); push_row(B, c.b); push_row(C, c.c); }
+    }
+};
+
+}}  // namespace zk::circuit

@@ -1,0 +1,205 @@
+// zklaim_circuit.hip — zklaim's credential circuit and public-input map on the host (no device code in this file).
+//
+// Replaces, for the prover path, what /root/reference/zklaim/snark.cpp:113-118 does with libsnark's protoboard:
+//     zklaim_gadget<FieldT> g(pb, ctx); g.generate_r1cs_constraints(); g.generate_r1cs_witness(ctx);
+// (zklaim/zklaim_gadget.cpp:153-784) and zklaim_input_map (zklaim_gadget.cpp:115-150).  The statement is the reference's:
+// per payload, SHA-256(pre) == hash for the 48-byte pre-image, each of the five 64-bit attributes stands in the relation
+// selected by the one-hot op to its reference value, exactly one op is selected per attribute, the compared values are
+// tied to plvars — and, like the reference, the pack_PL / pack_REF / pack_OPS packings are witness-only: their
+// constraints are never generated (zklaim_gadget.cpp:583-699 never calls them), so refvals / opsvals / plvars are not
+// bound to the public bits.  That quirk is reproduced, not repaired, unless ZKG_BIND_PACKINGS=1 is set.
+#include "common.hpp"
+#include "../../include/zkg.h"
+#include "../../include/zklaim_abi.h"
+#include "host/gadgets.hpp"
+#include <cstdlib>
+
+using namespace zk;
+using namespace zk::circuit;
+
+namespace {
+
+const size_t DIGEST = 256, FR_CAPACITY = 253;              // FieldT::capacity() of alt_bn128 Fr
+
+// memtobv (libsnark_wrapper.cpp:65-74): most significant bit of each byte first
+std::vector<bool> memtobv(const unsigned char *mem, size_t nbits) {
+    std::vector<bool> r(nbits);
+    for (size_t i = 0; i < nbits / 8; ++i) for (size_t k = 0; k < 8; ++k) r[i * 8 + k] = (mem[i] >> (7 - k)) & 1;
+    return r;
+}
+// set_zklaim_ops (zklaim_gadget.cpp:71-104): one-hot byte per operation inside an 8-byte slot
+void set_ops(unsigned char *buf, int op) {
+    switch (op) {
+    case zklaim_less: buf[0] = 1; break;          case zklaim_less_or_eq: buf[1] = 1; break;
+    case zklaim_eq: buf[2] = 1; break;            case zklaim_greater_or_eq: buf[3] = 1; break;
+    case zklaim_greater: buf[4] = 1; break;       case zklaim_not_eq: buf[5] = 1; break;
+    case zklaim_noop: buf[6] = 1; break;          default: break;
+    }
+}
+void payload_public_bytes(const zklaim_payload &pl, unsigned char refs[64], unsigned char ops[64]) {
+    memset(refs, 0, 64); memset(ops, 0, 64);
+    for (int j = 0; j < 5; ++j) { memcpy(refs + 8 * j, &pl.data_ref[j], 8); set_ops(ops + 8 * j, pl.data_op[j]); }
+}
+// the byte-reversed bit order zklaim_gadget uses for PL / REF / OPS (zklaim_gadget.cpp:447-469): within every byte the
+// bits are taken least significant first, so that 64 of them pack to the little-endian u64 of 8 bytes
+std::vector<Var> byte_lsb_first(const std::vector<Var> &bits) {
+    std::vector<Var> o; o.reserve(bits.size());
+    for (size_t l = 0; l < bits.size() / 8; ++l) for (int k = 7; k >= 0; --k) o.push_back(bits[l * 8 + k]);
+    return o;
+}
+
+}  // namespace
+
+struct zkg_circuit {
+    Builder pb;
+    Builder::Csr A, B, C;
+    std::vector<uint64_t> witness;
+    bool has_witness = false;
+};
+
+static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness) {
+    zkg_circuit *ck = new zkg_circuit();
+    Builder &pb = ck->pb;
+    const size_t k = ctx->num_of_payloads;
+    const bool bind_packings = getenv("ZKG_BIND_PACKINGS") != nullptr;
+    std::vector<const zklaim_payload *> pls;
+    for (const zklaim_wrap_payload_ctx *cur = ctx->pl_ctx_head; cur; cur = cur->next) pls.push_back(&cur->pl);
+    if (pls.size() != k) { delete ck; set_error("zklaim circuit: num_of_payloads disagrees with the payload list"); return nullptr; }
+
+    // ---- allocation, in the order of the reference's constructor (zklaim_gadget.cpp:348-540)
+    const size_t input_bits = DIGEST * k * 5;
+    const size_t n_inputs = (input_bits + FR_CAPACITY - 1) / FR_CAPACITY;
+    std::vector<Var> input_fe = pb.alloc_n(n_inputs);
+    pb.set_input_sizes((uint32_t)n_inputs);
+    Var zero = pb.alloc();
+    std::vector<std::array<Var, 5>> data(k), less(k), leq(k);
+    for (size_t i = 0; i < k; ++i) for (int j = 0; j < 5; ++j) { data[i][j] = pb.alloc(); less[i][j] = pb.alloc(); leq[i][j] = pb.alloc(); }
+    std::vector<Var> plvars = pb.alloc_n(6 * k), refvals = pb.alloc_n(8 * k), opsvals = pb.alloc_n(64 * k);
+    std::vector<std::vector<Var>> h_bits(k), ref_bits(k), ops_bits(k), r_bits(k);
+    std::vector<Var> input_as_bits;
+    for (size_t i = 0; i < k; ++i) {
+        h_bits[i] = pb.alloc_n(DIGEST); ref_bits[i] = pb.alloc_n(2 * DIGEST); ops_bits[i] = pb.alloc_n(2 * DIGEST);
+        for (auto *v : {&h_bits[i], &ref_bits[i], &ops_bits[i]}) input_as_bits.insert(input_as_bits.end(), v->begin(), v->end());
+    }
+    for (size_t i = 0; i < k; ++i) r_bits[i] = pb.alloc_n(DIGEST + 128);
+    std::vector<Var> PL, REF, OPS;
+    for (size_t i = 0; i < k; ++i) { auto t = byte_lsb_first(r_bits[i]); PL.insert(PL.end(), t.begin(), t.end()); }
+    for (size_t i = 0; i < k; ++i) { auto t = byte_lsb_first(ref_bits[i]); REF.insert(REF.end(), t.begin(), t.end()); }
+    for (size_t i = 0; i < k; ++i) { auto t = byte_lsb_first(ops_bits[i]); OPS.insert(OPS.end(), t.begin(), t.end()); }
+
+    // ---- witness values that do not depend on gadget internals (zklaim_gadget.cpp:705-783)
+    std::vector<std::array<uint64_t, 5>> attr(k), refv(k);
+    if (with_witness) {
+        pb.val[zero] = Fr::zero();
+        for (size_t i = 0; i < k; ++i) {
+            const zklaim_payload &pl = *pls[i];
+            unsigned char refs[64], ops[64];
+            payload_public_bytes(pl, refs, ops);
+            auto set_bits = [&](const std::vector<Var> &vars, const std::vector<bool> &bv) { for (size_t b = 0; b < vars.size(); ++b) pb.val[vars[b]] = bv[b] ? Fr::one() : Fr::zero(); };
+            set_bits(r_bits[i], memtobv(pl.pre, 384));
+            set_bits(h_bits[i], memtobv(pl.hash, 256));
+            set_bits(ref_bits[i], memtobv(refs, 512));
+            set_bits(ops_bits[i], memtobv(ops, 512));
+            for (int j = 0; j < 5; ++j) {
+                memcpy(&attr[i][j], pl.pre + 8 * j, 8);                        // extractFromBV: little-endian u64 of the slot
+                refv[i][j] = pl.data_ref[j];
+                pb.val[data[i][j]] = Fr::from_u64(attr[i][j]);
+            }
+        }
+        for (size_t c = 0; c < n_inputs; ++c) assign_packing(pb, input_as_bits, c * FR_CAPACITY, std::min(input_bits, (c + 1) * FR_CAPACITY), input_fe[c]);
+        for (size_t c = 0; c < 6 * k; ++c) assign_packing(pb, PL, c * 64, (c + 1) * 64, plvars[c]);
+        for (size_t c = 0; c < 8 * k; ++c) assign_packing(pb, REF, c * 64, (c + 1) * 64, refvals[c]);
+        for (size_t c = 0; c < 64 * k; ++c) assign_packing(pb, OPS, c * 8, (c + 1) * 8, opsvals[c]);
+    }
+
+    // ---- constraints (zklaim_gadget.cpp:583-699)
+    for (size_t c = 0; c < n_inputs; ++c)                                       // unpack_inputs, with booleanity of every public bit
+        enforce_packing(pb, input_as_bits, c * FR_CAPACITY, std::min(input_bits, (c + 1) * FR_CAPACITY), input_fe[c], true);
+    pb.enforce(LC::constant(1), LC(zero), LC());                               // zero == 0
+    if (bind_packings) {
+        for (size_t c = 0; c < 6 * k; ++c) enforce_packing(pb, PL, c * 64, (c + 1) * 64, plvars[c], false);
+        for (size_t c = 0; c < 8 * k; ++c) enforce_packing(pb, REF, c * 64, (c + 1) * 64, refvals[c], false);
+        for (size_t c = 0; c < 64 * k; ++c) enforce_packing(pb, OPS, c * 8, (c + 1) * 8, opsvals[c], false);
+    }
+    for (size_t i = 0; i < k; ++i) {
+        for (Var v : r_bits[i]) pb.enforce_boolean(v);                          // digest_variable r: booleanity
+        for (int j = 0; j < 5; ++j) {                                           // comparison_gadget(64, data_j, refvals[j + 8 i], less, less_or_eq)
+            Comparison cmp = comparison_alloc(pb, 64, leq[i][j]);
+            comparison_constraints(pb, cmp, 64, data[i][j], refvals[j + 8 * i], less[i][j], leq[i][j]);
+            if (with_witness) comparison_witness(pb, cmp, 64, attr[i][j], refv[i][j], less[i][j], leq[i][j]);
+        }
+        for (int j = 0; j < 5; ++j) {                                           // op selection: op * relation = op
+            auto op = [&](int o) { return LC(opsvals[o + j * 8 + i * 64]); };
+            LC L(less[i][j]), E(leq[i][j]), one = LC::constant(1);
+            pb.enforce(op(0), L, op(0));                                        // <
+            pb.enforce(op(1), E, op(1));                                        // <=
+            pb.enforce(op(2), E, op(2));                                        // == : <= ...
+            pb.enforce(op(2), L, LC());                                         //      ... and not <
+            pb.enforce(op(3), one - L, op(3));                                  // >=
+            pb.enforce(op(4), one - E, op(4));                                  // >
+            pb.enforce(op(5), L + (one - E), op(5));                            // !=
+            pb.enforce(op(6), one, op(6));                                      // noop
+        }
+        for (int j = 0; j < 5; ++j) {                                           // exactly one op per attribute
+            LC s; for (int o = 0; o < 7; ++o) s = s + LC(opsvals[o + j * 8 + i * 64]);
+            pb.enforce(LC::constant(1), s, LC::constant(1));
+        }
+        for (int j = 0; j < 5; ++j) pb.enforce(LC::constant(1), LC(data[i][j]) - LC(plvars[j + i * 6]), LC());   // input validation
+        // SHA-256(pre || padding) == hash: block = 384 pre-image bits + the fixed padding of a 48-byte message
+        std::vector<Bit> block(512);
+        for (size_t b = 0; b < 384; ++b) block[b] = Bit::var(r_bits[i][b]);
+        for (size_t b = 384; b < 512; ++b) block[b] = Bit::zero();
+        block[384] = Bit::one();                                                // 0x80
+        block[512 - 9] = Bit::one(); block[512 - 8] = Bit::one();              // length 384 = 0x0180, big-endian in the last 64 bits
+        sha256_compress_from_iv(pb, block, h_bits[i]);
+    }
+    pb.export_csr(ck->A, ck->B, ck->C);
+    if (with_witness) {
+        ck->has_witness = true;
+        ck->witness.resize((size_t)pb.num_variables() * 4);
+        for (uint32_t v = 1; v <= pb.num_variables(); ++v) memcpy(&ck->witness[4 * (size_t)(v - 1)], pb.val[v].v, 32);
+    }
+    return ck;
+}
+
+extern "C" {
+
+zkg_circuit *zkg_zklaim_circuit_new(const zklaim_ctx *ctx, int with_witness) {
+    if (!ctx) { set_error("zkg_zklaim_circuit_new: null ctx"); return nullptr; }
+    return build_zklaim(ctx, with_witness != 0);
+}
+void zkg_circuit_free(zkg_circuit *c) { delete c; }
+
+int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
+    if (!c || !out) return ZKG_ERROR;
+    memset(out, 0, sizeof(*out));
+    out->num_variables = c->pb.num_variables(); out->num_inputs = c->pb.num_inputs; out->num_constraints = (uint32_t)c->pb.cons.size();
+    out->a_rowptr = c->A.rowptr.data(); out->a_col = c->A.col.data(); out->a_val = c->A.val.data();
+    out->b_rowptr = c->B.rowptr.data(); out->b_col = c->B.col.data(); out->b_val = c->B.val.data();
+    out->c_rowptr = c->C.rowptr.data(); out->c_col = c->C.col.data(); out->c_val = c->C.val.data();
+    return ZKG_OK;
+}
+const uint64_t *zkg_circuit_witness(const zkg_circuit *c) { return (c && c->has_witness) ? c->witness.data() : nullptr; }
+int zkg_circuit_is_satisfied(const zkg_circuit *c) { return c && c->has_witness && c->pb.is_satisfied() ? 1 : 0; }
+long zkg_circuit_first_unsatisfied(const zkg_circuit *c) { return c ? (long)c->pb.first_unsatisfied() : -2; }
+
+// zklaim_input_map (zklaim_gadget.cpp:115-150): hash || refs(512 b) || ops(512 b) per payload, 253 bits per field element
+size_t zkg_zklaim_input_map(const zklaim_ctx *ctx, uint64_t *out, size_t cap_elems) {
+    if (!ctx) return 0;
+    std::vector<bool> bits;
+    for (const zklaim_wrap_payload_ctx *cur = ctx->pl_ctx_head; cur; cur = cur->next) {
+        unsigned char refs[64], ops[64];
+        payload_public_bytes(cur->pl, refs, ops);
+        for (auto &v : {memtobv(cur->pl.hash, 256), memtobv(refs, 512), memtobv(ops, 512)}) bits.insert(bits.end(), v.begin(), v.end());
+    }
+    size_t n = (bits.size() + FR_CAPACITY - 1) / FR_CAPACITY;
+    if (!out || cap_elems < n) return n;
+    for (size_t c = 0; c < n; ++c) {
+        Fr s = Fr::zero(), w = Fr::one();
+        for (size_t b = c * FR_CAPACITY; b < std::min(bits.size(), (c + 1) * FR_CAPACITY); ++b) { if (bits[b]) s += w; w = w.dbl(); }
+        memcpy(out + 4 * c, s.v, 32);
+    }
+    return n;
+}
+
+}  // extern "C"
