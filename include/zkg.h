@@ -159,6 +159,29 @@ int zkg_circuit_is_satisfied(const zkg_circuit *c);               /* pb.is_satis
 long zkg_circuit_first_unsatisfied(const zkg_circuit *c);         /* index of the first violated constraint, -1 if none    */
 size_t zkg_zklaim_input_map(const struct zklaim_ctx *ctx, uint64_t *out, size_t cap_elems);   /* returns the element count */
 
+/* ---- key generation and verification.
+ *      zkg_groth16_setup replaces r1cs_gg_ppzksnark_generator (snark.cpp:91): trapdoor = 5 x 4 canonical limbs
+ *      (t, alpha, beta, gamma, delta) or NULL for fresh randomness; the fixed-base exponentiations run on the GPU.
+ *      The blobs follow libsnark's operator<< layout for pk / vk (exported at libsnark_wrapper.cpp:122-157).
+ *      zkg_groth16_verify replaces r1cs_gg_ppzksnark_verifier_strong_IC (snark.cpp:62): 0 valid, 1 invalid, 2 malformed.   */
+typedef struct zkg_keypair zkg_keypair;
+zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor);
+void zkg_keypair_free(zkg_keypair *kp);
+const zkg_pk *zkg_keypair_pk(const zkg_keypair *kp);               /* flat arrays, valid until zkg_keypair_free              */
+int zkg_keypair_swapped(const zkg_keypair *kp);                    /* 1 if swap_AB_if_beneficial exchanged A and B          */
+size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);   /* returns the size needed / written       */
+size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
+int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs,
+                       const uint8_t *proof, size_t proof_len);
+int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]);   /* e(a*G1, b*G2), for bilinearity tests */
+
+/* ---- the reference's own seam (zklaim.h:257-259, libsnark_wrapper.cpp:195-276), same names and return codes, on
+ *      zklaim's zklaim_ctx (include/zklaim_abi.h): the three functions zklaim.c:77-91 calls.                               */
+int libsnark_trusted_setup(struct zklaim_ctx *ctx);
+int libsnark_prove(struct zklaim_ctx *ctx);
+int libsnark_verify(struct zklaim_ctx *ctx);
+void zkg_compat_reset(void);
+
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
  * average device ms per launch of the dominant kernel over the calls since the last reset */
 void  zkg_timing_reset(void);

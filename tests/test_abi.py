@@ -24,6 +24,8 @@ def test_library_exports_header_symbols():
         assert hasattr(lib, n), f"libzkg.so does not export {n}"
     import zklaim_amd
     assert sorted(zklaim_amd.DECLARED_SYMBOLS) == names
+    for n in zklaim_amd.COMPAT_SYMBOLS:                      # the reference's own seam names (zklaim.h:257-259)
+        assert hasattr(lib, n), n
 
 
 def test_no_cpu_fallback():

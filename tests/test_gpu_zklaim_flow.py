@@ -1,0 +1,108 @@
+"""GPU suite: key generation on the GPU and the reference's own seam libsnark_trusted_setup / libsnark_prove / libsnark_verify on a
+zklaim_ctx — mirrors the reference's integration tests (zklaim/tests/zklaim.cpp: can_do_ts :32-55, can_proof :222-258,
+can_handle_two_payloads :260-298, can_handle_three_payloads :300-339, can_handle_no_payload :341-353, three_party_run :413-504),
+which assert return codes, plus what they leave out: rejected proofs and forged public values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpu_util import zkg  # noqa: F401
+from r1cs_util import golden_case_arrays
+from util import arr, golden, h, random_fr_canonical
+
+pytestmark = pytest.mark.gpu
+CASES = golden("groth16.json")
+
+
+@pytest.mark.parametrize("case", CASES[:3], ids=[c["tag"] for c in CASES[:3]])
+def test_setup_matches_oracle_generator(zkg, oracle, case):
+    """same trapdoor -> the GPU fixed-base generator and the oracle's r1cs_gg_ppzksnark_generator restatement give identical keys"""
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    cs = zkg.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
+    td = arr([h(case["trapdoor"][k]) for k in ("t", "alpha", "beta", "gamma", "delta")])
+    kp = zkg.Keypair(cs, td)
+    assert not kp.swapped                                    # the golden systems are stored already swapped
+    n, l, m = case["num_variables"], case["num_inputs"], case["m"]
+    for name, count, limbs_ in (("A_query", n + 1, 8), ("B_g1", n + 1, 8), ("B_g2", n + 1, 16), ("H_query", m - 1, 8), ("L_query", n - l, 8),
+                                ("alpha_g1", 1, 8), ("beta_g1", 1, 8), ("delta_g1", 1, 8), ("beta_g2", 1, 16), ("delta_g2", 1, 16)):
+        assert np.array_equal(kp.array(name, count, limbs_).reshape(-1), pts[name].reshape(-1)), name
+    # pk blob -> resident CRS -> the golden proof; vk blob verifies it
+    crs = zkg.Crs(blob=kp.pk_blob(), m=m)
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    assert zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
+    bad = bytearray(proof); bad[50] ^= 4
+    assert zkg.groth16_verify(kp.vk_blob(), w[:l], bytes(bad)) != 0
+    crs.free(); kp.free()
+
+
+def test_swap_ab_if_beneficial(zkg, oracle):
+    """a system whose B side touches more variables gets A and B exchanged before the QAP evaluation"""
+    keep = []
+    from util import R
+    one = arr([1], R)
+    # x1 * (x2 + x3 + x4) = x5 : A touches 1 variable, B touches 3
+    A = (np.array([0, 1], np.uint32), np.array([1], np.uint32), one)
+    B = (np.array([0, 3], np.uint32), np.array([2, 3, 4], np.uint32), np.concatenate([one] * 3))
+    Cm = (np.array([0, 1], np.uint32), np.array([5], np.uint32), one)
+    cs = zkg.make_r1cs(5, 1, A, B, Cm, keep)
+    kp = zkg.Keypair(cs, random_fr_canonical(5, 3))
+    assert kp.swapped
+    kp.free()
+
+
+def payload(ops, refs, attrs, salt):
+    return dict(attrs=attrs, refs=refs, ops=ops, salt=salt)
+
+
+def run_flow(zkg, pls, expect_prove=0):
+    keep = []
+    ctx = zkg.make_ctx(pls, keep)
+    assert zkg.libsnark_trusted_setup(ctx) == 0                                   # can_do_ts
+    assert ctx.pk_size > 0 and ctx.vk_size > 0
+    rc = zkg.libsnark_prove(ctx)
+    assert rc == expect_prove
+    return ctx, keep
+
+
+def test_can_proof_and_three_party_run(zkg):
+    pls = [payload(["less", "eq", "greater", "noop", "greater_or_eq"], [2000, 7, 41, 5, 5], [1994, 7, 42, 0, 5], 0x1111)]
+    ctx, keep = run_flow(zkg, pls)
+    assert ctx.proof_size == 134
+    assert zkg.libsnark_verify(ctx) == 0                                           # three_party_run: the verifier accepts
+    # a second proof on the same key reuses the resident CRS and differs (fresh r, s) but verifies
+    p1 = zkg.ctx_blob(ctx, "proof")
+    assert zkg.libsnark_prove(ctx) == 0
+    p2 = zkg.ctx_blob(ctx, "proof")
+    assert p1 != p2 and zkg.libsnark_verify(ctx) == 0
+    # verifier side with a forged public reference value (the claim "attr0 < 2000" replaced by "attr0 < 1000"): rejected
+    head = ctx.pl_ctx_head.contents
+    head.pl.data_ref[0] = 1000
+    assert zkg.libsnark_verify(ctx) != 0
+    head.pl.data_ref[0] = 2000
+    assert zkg.libsnark_verify(ctx) == 0
+    # tampered proof bytes: rejected
+    buf = (C.c_ubyte * 134).from_address(ctx.proof)
+    buf[20] ^= 1
+    assert zkg.libsnark_verify(ctx) != 0
+    buf[20] ^= 1
+    assert zkg.libsnark_verify(ctx) == 0
+    # the public clone of the credential (pre-images cleared, as zklaim_clear_pres does) still verifies
+    head.pl.pre[:] = [0] * 48; head.pl.salt = 0
+    assert zkg.libsnark_verify(ctx) == 0
+
+
+def test_unsatisfied_credential_returns_1(zkg):
+    pls = [payload(["greater", "noop", "noop", "noop", "noop"], [2000, 0, 0, 0, 0], [1994, 1, 2, 3, 4], 7)]     # 1994 > 2000 is false
+    run_flow(zkg, pls, expect_prove=1)
+
+
+@pytest.mark.parametrize("k", [0, 2, 3])
+def test_payload_counts(zkg, k):
+    """can_handle_no_payload / two / three payloads: setup + prove succeed, and the proof verifies"""
+    pls = [payload(["less_or_eq", "not_eq", "noop", "noop", "noop"], [30 + i, 9, 0, 0, 0], [30 + i, 8, i, 2, 3], 100 + i) for i in range(k)]
+    ctx, keep = run_flow(zkg, pls)
+    assert zkg.libsnark_verify(ctx) == 0
+    zkg.lib().zkg_compat_reset()

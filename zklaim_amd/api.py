@@ -17,8 +17,12 @@ DECLARED_SYMBOLS = [
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
-    "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map",
+    "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
+    "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe",
+    "zkg_compat_reset",
 ]
+# the reference's own seam, exported with its original names (zklaim.h:257-259)
+COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
 
 
 class ZkgError(RuntimeError):
@@ -341,3 +345,69 @@ def zklaim_input_map(ctx):
     out = np.zeros((n, 4), np.uint64)
     L.zkg_zklaim_input_map(C.cast(C.pointer(ctx), C.c_void_p), _p(out), n)
     return out
+
+
+# ---- key generation / verification (r1cs_gg_ppzksnark_generator, r1cs_gg_ppzksnark_verifier_strong_IC) ------------------
+class Keypair:
+    def __init__(self, r1cs, trapdoor=None):
+        L = lib()
+        L.zkg_groth16_setup.restype = C.c_void_p
+        L.zkg_groth16_setup.argtypes = [C.c_void_p, C.c_void_p]
+        L.zkg_keypair_pk.restype = C.POINTER(PK)
+        for f in (L.zkg_keypair_pk, L.zkg_keypair_free, L.zkg_keypair_swapped):
+            f.argtypes = [C.c_void_p]
+        for f in (L.zkg_keypair_pk_blob, L.zkg_keypair_vk_blob):
+            f.restype = C.c_size_t; f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        td = None if trapdoor is None else _u64(trapdoor)
+        self._h = L.zkg_groth16_setup(C.byref(r1cs), _p(td))
+        if not self._h:
+            raise ZkgError("zkg_groth16_setup failed: " + L.zkg_last_error().decode())
+        self.pk = L.zkg_keypair_pk(self._h).contents
+        self.swapped = bool(L.zkg_keypair_swapped(self._h))
+
+    def _blob(self, fn):
+        n = fn(self._h, None, 0)
+        out = np.zeros(n, np.uint8)
+        assert fn(self._h, _p(out), n) == n
+        return out.tobytes()
+
+    def pk_blob(self): return self._blob(lib().zkg_keypair_pk_blob)
+    def vk_blob(self): return self._blob(lib().zkg_keypair_vk_blob)
+
+    def array(self, name, count, limbs):
+        return np.ctypeslib.as_array(C.cast(getattr(self.pk, name), C.POINTER(C.c_uint64)), shape=(count, limbs)).copy()
+
+    def free(self):
+        if self._h:
+            lib().zkg_keypair_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def groth16_verify(vk_blob, primary_input, proof):
+    """0 valid, 1 invalid, 2 malformed (host pairing; no GPU needed)"""
+    L = lib()
+    L.zkg_groth16_verify.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    vk = np.frombuffer(vk_blob, np.uint8).copy(); pr = np.frombuffer(proof, np.uint8).copy()
+    x = _u64(primary_input)
+    return L.zkg_groth16_verify(_p(vk), vk.size, _p(x) if x.size else None, x.size // 4, _p(pr), pr.size)
+
+
+def pairing_probe(a, b):
+    out = np.zeros(384, np.uint8)
+    lib().zkg_pairing_probe(_p(_u64(a)), _p(_u64(b)), _p(out))
+    return out.tobytes()
+
+
+def libsnark_trusted_setup(ctx): return lib().libsnark_trusted_setup(C.byref(ctx))
+def libsnark_prove(ctx): return lib().libsnark_prove(C.byref(ctx))
+def libsnark_verify(ctx): return lib().libsnark_verify(C.byref(ctx))
+
+
+def ctx_blob(ctx, which):
+    size = getattr(ctx, which + "_size"); ptr = getattr(ctx, which)
+    return C.string_at(ptr, size) if ptr and size else b""

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libzkg.so")
-SOURCES = ["ntt.hip", "msm.hip", "prover.hip", "codec.hip", "zklaim_circuit.hip", "capi.hip"]
+SOURCES = ["ntt.hip", "msm.hip", "prover.hip", "codec.hip", "zklaim_circuit.hip", "setup_verify.hip", "compat.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

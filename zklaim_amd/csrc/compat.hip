@@ -1,0 +1,131 @@
+// compat.hip — the seam zklaim's C front-end links against, unchanged in name, signature and return codes:
+//     int libsnark_trusted_setup(zklaim_ctx*), int libsnark_prove(zklaim_ctx*), int libsnark_verify(zklaim_ctx*)
+// (declared /root/reference/zklaim/zklaim.h:257-259, defined zklaim/libsnark_wrapper.cpp:195-276, called from
+// zklaim_trusted_setup / zklaim_proof_generate / zklaim_proof_verify at zklaim/zklaim.c:77-91).
+// Behaviour kept: 0 on success; prove returns 1 for an unsatisfied credential (libsnark_wrapper.cpp:233-240); verify returns
+// !valid (:269); ctx->pk / vk / proof are malloc'd here and freed by zklaim_ctx_free (zklaim.c:57-72).
+// Behaviour changed on purpose: file descriptor 1 is never closed (the reference closes stdout around every call,
+// :199-203,220-225,254-258), nothing is re-initialised per call, and the parsed key stays resident on the GPU between proofs
+// of the same ctx->pk instead of being re-parsed (:230).
+#include "common.hpp"
+#include "../../include/zkg.h"
+#include "../../include/zklaim_abi.h"
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
+
+using namespace zk;
+
+extern "C" {
+struct zkg_keypair;
+zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor);
+void zkg_keypair_free(zkg_keypair *kp);
+size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
+size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
+int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len);
+}
+
+namespace {
+
+std::mutex g_mu;
+bool g_inited = false;
+struct CachedCrs { uint64_t digest; size_t size; zkg_crs *crs; };
+std::map<uint64_t, CachedCrs> g_crs_cache;                    // keyed by a digest of ctx->pk: one upload per key, not per proof
+
+int ensure_init() {
+    if (g_inited) return 0;
+    const char *dev = getenv("ZKG_DEVICE");
+    if (zkg_init(dev ? atoi(dev) : 0)) return 1;
+    g_inited = true;
+    return 0;
+}
+uint64_t digest(const unsigned char *p, size_t n) {            // FNV-1a over the whole blob (~1 GB/s; the blob is read once anyway)
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h ^ n;
+}
+void random_fr_mont(uint64_t out[4]) {
+    std::random_device rd;
+    for (;;) {
+        uint32_t v[8]; for (auto &x : v) x = rd();
+        v[7] &= 0x3fffffffu;
+        bool lt = false;
+        for (int i = 7; i >= 0; --i) if (v[i] != FrParams::P[i]) { lt = v[i] < FrParams::P[i]; break; }
+        if (lt) { memcpy(out, v, 32); return; }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int libsnark_trusted_setup(zklaim_ctx *ctx) {
+    if (!ctx) return ZKLAIM_ERROR;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ensure_init()) return ZKLAIM_ERROR;
+    zkg_circuit *ck = zkg_zklaim_circuit_new(ctx, 0);             // generate_keypair: gadget + constraints only (snark.cpp:76-92)
+    if (!ck) return ZKLAIM_ERROR;
+    zkg_r1cs cs;
+    zkg_keypair *kp = zkg_circuit_r1cs(ck, &cs) == 0 ? zkg_groth16_setup(&cs, nullptr) : nullptr;
+    zkg_circuit_free(ck);
+    if (!kp) return ZKLAIM_ERROR;
+    size_t vk_len = zkg_keypair_vk_blob(kp, nullptr, 0), pk_len = zkg_keypair_pk_blob(kp, nullptr, 0);
+    unsigned char *vk = (unsigned char *)malloc(vk_len), *pk = (unsigned char *)malloc(pk_len);
+    int rc = ZKLAIM_ERROR;
+    if (vk && pk && zkg_keypair_vk_blob(kp, vk, vk_len) == vk_len && zkg_keypair_pk_blob(kp, pk, pk_len) == pk_len) {
+        ctx->vk = vk; ctx->vk_size = vk_len; ctx->pk = pk; ctx->pk_size = pk_len;                 // libsnark_wrapper.cpp:207-208
+        rc = ZKLAIM_OK;
+    } else { free(vk); free(pk); }
+    zkg_keypair_free(kp);
+    return rc;
+}
+
+int libsnark_prove(zklaim_ctx *ctx) {
+    if (!ctx || !ctx->pk || !ctx->pk_size) return ZKLAIM_ERROR;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ensure_init()) return ZKLAIM_ERROR;
+    uint64_t d = digest(ctx->pk, ctx->pk_size);
+    zkg_crs *crs = nullptr;
+    auto it = g_crs_cache.find(d);
+    if (it != g_crs_cache.end() && it->second.size == ctx->pk_size) crs = it->second.crs;
+    else {
+        crs = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
+        if (!crs) return ZKLAIM_ERROR;
+        if (g_crs_cache.size() >= 4) { for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs); g_crs_cache.clear(); }
+        g_crs_cache[d] = {d, ctx->pk_size, crs};
+    }
+    zkg_circuit *ck = zkg_zklaim_circuit_new(ctx, 1);             // gadget + constraints + witness (snark.cpp:113-118)
+    if (!ck) return ZKLAIM_ERROR;
+    int rc = ZKLAIM_ERROR;
+    if (!zkg_circuit_is_satisfied(ck)) rc = 1;                    // "system not satisfied!! not creating proof." (snark.cpp:121-124)
+    else {
+        uint64_t r[4], s[4];
+        random_fr_mont(r); random_fr_mont(s);
+        unsigned char *proof = (unsigned char *)malloc(ZKG_PROOF_BYTES);
+        size_t len = 0;
+        int prc = proof ? zkg_groth16_prove(crs, zkg_circuit_witness(ck), r, s, 0, proof, &len) : ZKG_ERROR;
+        if (prc == ZKG_OK) { ctx->proof = proof; ctx->proof_size = len; rc = ZKLAIM_OK; }      // libsnark_wrapper.cpp:242
+        else free(proof);
+    }
+    zkg_circuit_free(ck);
+    return rc;
+}
+
+int libsnark_verify(zklaim_ctx *ctx) {
+    if (!ctx || !ctx->vk || !ctx->proof) return 1;
+    size_t n = zkg_zklaim_input_map(ctx, nullptr, 0);
+    std::vector<uint64_t> input(4 * n + 4);
+    zkg_zklaim_input_map(ctx, input.data(), n);                   // verify_proof: input = zklaim_input_map(ctx) (snark.cpp:58-62)
+    return zkg_groth16_verify(ctx->vk, ctx->vk_size, input.data(), n, ctx->proof, ctx->proof_size) == 0 ? 0 : 1;
+}
+
+// drops the resident keys cached by libsnark_prove (tests / long-running hosts)
+void zkg_compat_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs);
+    g_crs_cache.clear();
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// setup_verify.hip — Groth16 key generation and verification for the zklaim seam.
+//
+// Replaces r1cs_gg_ppzksnark_generator (/root/reference/zklaim/snark.cpp:91, reached from libsnark_trusted_setup,
+// zklaim/libsnark_wrapper.cpp:195-215) and r1cs_gg_ppzksnark_verifier_strong_IC (snark.cpp:62, reached from libsnark_verify,
+// libsnark_wrapper.cpp:252-276), plus the vk / pk blob export (libsnark_wrapper.cpp:122-157).
+//
+// Generator: swap A and B when B touches more variables (libsnark's swap_AB_if_beneficial: fewer G2 bases), evaluate the QAP
+// at the trapdoor point t on the host (Lagrange coefficients in closed form with one batched inversion, then one pass over
+// the non-zeros), and turn the ~4n + m scalars into curve points with the fixed-base kernels of msm.hip on the GPU — the part
+// that dominates the reference's setup time.  Domain: m = next power of two >= C + l + 1 (libfqfft would pick a
+// step_radix2 domain for some sizes; this build always uses basic radix-2 domains).
+// Verifier: host pairing (host/pairing.hpp); the public input is folded into gamma_ABC with host scalar multiplications.
+#include "common.hpp"
+#include "../../include/zkg.h"
+#include "host/serialize.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+using namespace zk;
+using zk::pairing::Fq12;
+
+struct zkg_keypair {
+    // the (possibly swapped) constraint system stored in the pk
+    std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
+    uint32_t n = 0, l = 0, C = 0, log_m = 0; bool swapped = false;
+    G1Affine alpha_g1, beta_g1, delta_g1; G2Affine beta_g2, delta_g2, gamma_g2;
+    std::vector<G1Affine> A_query, B_g1, H_query, L_query, IC;
+    std::vector<G2Affine> B_g2;
+    Fq12 alpha_beta;
+    zkg_pk pk_view;
+};
+
+namespace {
+
+Fr fr_from_canonical(const uint64_t *limbs) { Fr x; memcpy(x.v, limbs, 32); return x.to_mont(); }
+
+Fr random_fr() {
+    std::random_device rd;                                   // the reference draws its toxic waste from std::random_device too
+    for (;;) {
+        Fr x;
+        for (int i = 0; i < 8; ++i) x.v[i] = rd();
+        x.v[7] &= 0x3fffffffu;
+        bool lt = false;
+        for (int i = 7; i >= 0; --i) { if (x.v[i] != FrParams::P[i]) { lt = x.v[i] < FrParams::P[i]; break; } }
+        if (lt && !x.is_zero()) return x;                    // uniform in [1, r); reading it as a Montgomery residue keeps it uniform
+    }
+}
+
+void copy_csr(std::vector<uint32_t> &rp, std::vector<uint32_t> &col, std::vector<uint64_t> &val, const uint32_t *s_rp, const uint32_t *s_col, const uint64_t *s_val, uint32_t rows) {
+    rp.assign(s_rp, s_rp + rows + 1);
+    size_t nnz = s_rp[rows];
+    col.assign(s_col, s_col + nnz);
+    val.assign(s_val, s_val + 4 * nnz);
+}
+
+template <class A, class FN>
+int batch_points(FN fixed_base_fn, const A &base, const std::vector<Fr> &scalars, std::vector<A> &out) {
+    size_t n = scalars.size();
+    out.assign(n, A::inf());
+    if (!n) return ZKG_OK;
+    std::vector<uint32_t> canon(n * 8);
+    for (size_t i = 0; i < n; ++i) { Fr c = scalars[i].from_mont(); memcpy(&canon[8 * i], c.v, 32); }
+    DevBuf d_s, d_o;
+    if (d_s.reserve(n * 32) || d_o.reserve(n * sizeof(A))) return ZKG_ERROR;
+    int rc = ZKG_ERROR;
+    if (hip_ok(hipMemcpy(d_s.p, canon.data(), n * 32, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+        fixed_base_fn(base, d_s.as<uint32_t>(), n, d_o.as<A>(), nullptr) == ZKG_OK &&
+        hip_ok(hipMemcpy(out.data(), d_o.p, n * sizeof(A), hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) rc = ZKG_OK;
+    d_s.release(); d_o.release();
+    return rc;
+}
+
+G1Affine g1_generator() { return {Fq::from_u64(1), Fq::from_u64(2)}; }
+G2Affine g2_generator() {
+    auto limbs = [](std::initializer_list<uint32_t> l) { Fq x; int i = 0; for (uint32_t v : l) x.v[i++] = v; return x; };
+    return {{limbs({0x02bc2026u, 0x8e83b5d1u, 0x497b0172u, 0xdceb1935u, 0x97811adfu, 0xfbb82647u, 0xaf96503bu, 0x19573841u}),
+             limbs({0xa84c6140u, 0xafb4737du, 0x5802d8c4u, 0x6043dd5au, 0x52a02f86u, 0x09e950fcu, 0x3aea7b6bu, 0x14fef083u})},
+            {limbs({0x886be9f6u, 0x619dfa9du, 0xf59e9b78u, 0xfe7fd297u, 0x231b7dfeu, 0xff9e1a62u, 0xae9e4206u, 0x28fd7eebu}),
+             limbs({0xc71856eeu, 0x64095b56u, 0x327d3cbbu, 0xdc57f922u, 0x33351076u, 0x55f935beu, 0x93fd6482u, 0x0da4a0e6u})}};
+}
+Fr fr_root_of_unity_2p28() {
+    Fr r; const uint32_t l[8] = {0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u, 0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u};
+    for (int i = 0; i < 8; ++i) r.v[i] = l[i];
+    return r;
+}
+void fr_limbs(const Fr &x, uint32_t out[8]) { Fr c = x.from_mont(); memcpy(out, c.v, 32); }
+
+}  // namespace
+
+extern "C" {
+
+zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5 x 4 canonical limbs: t, alpha, beta, gamma, delta; NULL = random */) {
+    if (!cs || !cs->a_rowptr || !cs->b_rowptr || !cs->c_rowptr) { set_error("zkg_groth16_setup: null constraint system"); return nullptr; }
+    zkg_keypair *kp = new zkg_keypair();
+    kp->n = cs->num_variables; kp->l = cs->num_inputs; kp->C = cs->num_constraints;
+    const size_t n = kp->n, l = kp->l, C = kp->C;
+    copy_csr(kp->rp[0], kp->col[0], kp->val[0], cs->a_rowptr, cs->a_col, cs->a_val, kp->C);
+    copy_csr(kp->rp[1], kp->col[1], kp->val[1], cs->b_rowptr, cs->b_col, cs->b_val, kp->C);
+    copy_csr(kp->rp[2], kp->col[2], kp->val[2], cs->c_rowptr, cs->c_col, cs->c_val, kp->C);
+    {   // swap_AB_if_beneficial: count the variables each of A and B touches
+        std::vector<char> ta(n + 1, 0), tb(n + 1, 0);
+        for (uint32_t c : kp->col[0]) ta[c] = 1;
+        for (uint32_t c : kp->col[1]) tb[c] = 1;
+        size_t na = 0, nb = 0;
+        for (size_t i = 0; i <= n; ++i) { na += ta[i]; nb += tb[i]; }
+        if (nb > na) { kp->rp[0].swap(kp->rp[1]); kp->col[0].swap(kp->col[1]); kp->val[0].swap(kp->val[1]); kp->swapped = true; }
+    }
+    size_t need = C + l + 1; unsigned log_m = 1; while (((size_t)1 << log_m) < need) ++log_m;
+    if (log_m > 28) { set_error("zkg_groth16_setup: system too large for the 2-adicity of Fr"); delete kp; return nullptr; }
+    kp->log_m = log_m;
+    const size_t m = (size_t)1 << log_m;
+    Fr t, alpha, beta, gamma, delta;
+    if (trapdoor) { t = fr_from_canonical(trapdoor); alpha = fr_from_canonical(trapdoor + 4); beta = fr_from_canonical(trapdoor + 8); gamma = fr_from_canonical(trapdoor + 12); delta = fr_from_canonical(trapdoor + 16); }
+    else { t = random_fr(); alpha = random_fr(); beta = random_fr(); gamma = random_fr(); delta = random_fr(); }
+    // ---- Lagrange coefficients u_i = Z(t) w^i / (m (t - w^i)) with one batched inversion
+    Fr omega = fr_root_of_unity_2p28();
+    for (unsigned i = 28; i > log_m; --i) omega = omega.sqr();
+    Fr Zt = t.pow_u64(m) - Fr::one();
+    std::vector<Fr> u(m), den(m), pre(m);
+    {
+        Fr wi = Fr::one(), mf = Fr::from_u64(m), run = Fr::one();
+        for (size_t i = 0; i < m; ++i) { u[i] = Zt * wi; den[i] = mf * (t - wi); if (den[i].is_zero()) { set_error("zkg_groth16_setup: t is a domain point"); delete kp; return nullptr; } pre[i] = run; run = run * den[i]; wi = wi * omega; }
+        Fr inv = run.inverse();
+        for (size_t i = m; i-- > 0;) { Fr di = inv * pre[i]; inv = inv * den[i]; u[i] = u[i] * di; }
+    }
+    // ---- QAP polynomials at t (r1cs_to_qap_instance_map_with_evaluation)
+    std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
+    for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
+    std::vector<Fr> *dst[3] = {&At, &Bt, &Ct};
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < C; ++i)
+            for (uint32_t e = kp->rp[k][i]; e < kp->rp[k][i + 1]; ++e) { Fr c; memcpy(c.v, &kp->val[k][4 * (size_t)e], 32); (*dst[k])[kp->col[k][e]] += u[i] * c; }
+    Fr dinv = delta.inverse(), ginv = gamma.inverse();
+    std::vector<Fr> Hs(m - 1), Ls(n - l), ICs(l + 1);
+    { Fr ti = Fr::one(), zd = Zt * dinv; for (size_t i = 0; i + 1 < m; ++i) { Hs[i] = ti * zd; ti = ti * t; } }
+    for (size_t i = 0; i <= n; ++i) {
+        Fr abc = beta * At[i] + alpha * Bt[i] + Ct[i];
+        if (i <= l) ICs[i] = abc * ginv; else Ls[i - l - 1] = abc * dinv;
+    }
+    // ---- scalars -> points (GPU fixed-base batches)
+    G1Affine g1 = g1_generator(); G2Affine g2 = g2_generator();
+    std::vector<G1Affine> small1; std::vector<G2Affine> small2;
+    bool ok = batch_points<G1Affine>(fixed_base_g1, g1, {alpha, beta, delta}, small1) == 0 && batch_points<G2Affine>(fixed_base_g2, g2, {beta, delta, gamma}, small2) == 0 &&
+              batch_points<G1Affine>(fixed_base_g1, g1, At, kp->A_query) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Bt, kp->B_g1) == 0 &&
+              batch_points<G2Affine>(fixed_base_g2, g2, Bt, kp->B_g2) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Hs, kp->H_query) == 0 &&
+              batch_points<G1Affine>(fixed_base_g1, g1, Ls, kp->L_query) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, ICs, kp->IC) == 0;
+    if (!ok) { delete kp; return nullptr; }
+    kp->alpha_g1 = small1[0]; kp->beta_g1 = small1[1]; kp->delta_g1 = small1[2];
+    kp->beta_g2 = small2[0]; kp->delta_g2 = small2[1]; kp->gamma_g2 = small2[2];
+    kp->alpha_beta = pairing::reduced_pairing(kp->alpha_g1, kp->beta_g2);
+    zkg_pk &v = kp->pk_view; memset(&v, 0, sizeof(v));
+    v.cs.num_variables = kp->n; v.cs.num_inputs = kp->l; v.cs.num_constraints = kp->C;
+    v.cs.a_rowptr = kp->rp[0].data(); v.cs.a_col = kp->col[0].data(); v.cs.a_val = kp->val[0].data();
+    v.cs.b_rowptr = kp->rp[1].data(); v.cs.b_col = kp->col[1].data(); v.cs.b_val = kp->val[1].data();
+    v.cs.c_rowptr = kp->rp[2].data(); v.cs.c_col = kp->col[2].data(); v.cs.c_val = kp->val[2].data();
+    v.log_m = log_m;
+    v.alpha_g1 = (const uint64_t *)&kp->alpha_g1; v.beta_g1 = (const uint64_t *)&kp->beta_g1; v.delta_g1 = (const uint64_t *)&kp->delta_g1;
+    v.beta_g2 = (const uint64_t *)&kp->beta_g2; v.delta_g2 = (const uint64_t *)&kp->delta_g2;
+    v.A_query = (const uint64_t *)kp->A_query.data(); v.B_g1 = (const uint64_t *)kp->B_g1.data(); v.B_g2 = (const uint64_t *)kp->B_g2.data();
+    v.H_query = (const uint64_t *)kp->H_query.data(); v.L_query = (const uint64_t *)kp->L_query.data();
+    return kp;
+}
+
+void zkg_keypair_free(zkg_keypair *kp) { delete kp; }
+const zkg_pk *zkg_keypair_pk(const zkg_keypair *kp) { return kp ? &kp->pk_view : nullptr; }
+int zkg_keypair_swapped(const zkg_keypair *kp) { return kp && kp->swapped ? 1 : 0; }
+
+// operator<<(r1cs_gg_ppzksnark_proving_key), layout in codec.hip
+size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
+    if (!kp) return 0;
+    ser::Writer w;
+    w.g1(kp->alpha_g1); w.g1(kp->beta_g1); w.g2(kp->beta_g2); w.g1(kp->delta_g1); w.g2(kp->delta_g2);
+    w.dec(kp->A_query.size()); for (auto &p : kp->A_query) w.g1(p);
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < kp->B_g2.size(); ++i) if (!kp->B_g2[i].is_inf() || !kp->B_g1[i].is_inf()) idx.push_back(i);
+    w.dec(kp->B_g2.size()); w.dec(idx.size()); for (size_t i : idx) w.dec(i);
+    w.dec(idx.size()); for (size_t i : idx) { w.g2(kp->B_g2[i]); w.g1(kp->B_g1[i]); }
+    w.dec(kp->H_query.size()); for (auto &p : kp->H_query) w.g1(p);
+    w.dec(kp->L_query.size()); for (auto &p : kp->L_query) w.g1(p);
+    w.dec(kp->l); w.dec(kp->n - kp->l); w.dec(kp->C);
+    for (uint32_t c = 0; c < kp->C; ++c)
+        for (int k = 0; k < 3; ++k) {
+            w.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
+            for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { w.dec(kp->col[k][e]); w.raw(&kp->val[k][4 * (size_t)e], 32); }
+        }
+    if (out && cap >= w.buf.size()) memcpy(out, w.buf.data(), w.buf.size());
+    return w.buf.size();
+}
+
+// operator<<(r1cs_gg_ppzksnark_verification_key): alpha_g1_beta_g2 (GT, 384 B) | gamma_g2 | delta_g2 | gamma_ABC_g1 as an
+// accumulation_vector: first (G1) then a sparse vector: domain '\n' #indices '\n' (index '\n')* #values '\n' (G1)*
+size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
+    if (!kp) return 0;
+    ser::Writer w;
+    uint8_t gt[384]; ser::put_fq12(gt, kp->alpha_beta); w.raw(gt, 384);
+    w.g2(kp->gamma_g2); w.g2(kp->delta_g2);
+    w.g1(kp->IC[0]);
+    size_t rest = kp->IC.size() - 1;
+    w.dec(rest); w.dec(rest); for (size_t i = 0; i < rest; ++i) w.dec(i);
+    w.dec(rest); for (size_t i = 0; i < rest; ++i) w.g1(kp->IC[i + 1]);
+    if (out && cap >= w.buf.size()) memcpy(out, w.buf.data(), w.buf.size());
+    return w.buf.size();
+}
+
+// r1cs_gg_ppzksnark_verifier_strong_IC: 0 = proof valid, 1 = invalid (libsnark_verify returns !valid, libsnark_wrapper.cpp:269),
+// 2 = malformed key / proof.  primary_input: n_inputs x 4 limbs, Montgomery Fr.
+int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
+    if (!vk_blob || !proof || (n_inputs && !primary_input)) { set_error("zkg_groth16_verify: null argument"); return 2; }
+    ser::Reader rd{vk_blob, vk_blob + vk_len};
+    const uint8_t *gt = rd.take(384), *pg = rd.take(66), *pd = rd.take(66), *p0 = rd.take(34);
+    if (!rd.ok) { set_error("vk blob truncated"); return 2; }
+    Fq12 alpha_beta; ser::get_fq12(gt, alpha_beta);
+    G2Affine gamma_g2, delta_g2; G1Affine ic0;
+    if (!ser::get_g2(pg, gamma_g2) || !ser::get_g2(pd, delta_g2) || !ser::get_g1(p0, ic0)) { set_error("vk blob: bad point"); return 2; }
+    size_t domain = rd.dec(), nidx = rd.dec();
+    if (!rd.ok || nidx > domain) { set_error("vk blob: bad gamma_ABC header"); return 2; }
+    std::vector<size_t> idx(nidx);
+    for (auto &i : idx) { i = rd.dec(); if (!rd.ok || i >= domain) { set_error("vk blob: bad index"); return 2; } }
+    size_t nval = rd.dec(); const uint8_t *vals = rd.take(nval * 34);
+    if (!rd.ok || nval != nidx) { set_error("vk blob: bad gamma_ABC values"); return 2; }
+    if (domain != n_inputs) return 1;                                           // strong input consistency: sizes must agree
+    if (proof_len != ZKG_PROOF_BYTES) return 1;
+    G1Affine pA, pC; G2Affine pB;
+    if (!ser::get_g1(proof, pA) || !ser::get_g2(proof + 34, pB) || !ser::get_g1(proof + 100, pC)) return 1;     // is_well_formed
+    // acc = IC_0 + sum_i input_i * IC_{i+1}
+    G1 acc = G1::from_affine(ic0);
+    for (size_t k = 0; k < nidx; ++k) {
+        G1Affine p; if (!ser::get_g1(vals + 34 * k, p)) { set_error("vk blob: bad gamma_ABC point"); return 2; }
+        Fr x; memcpy(x.v, primary_input + 4 * idx[k], 32);
+        uint32_t e[8]; fr_limbs(x, e);
+        acc.add(G1::from_affine(p).mul(e, 8));
+    }
+    // e(A, B) == e(alpha, beta) * e(acc, gamma) * e(C, delta)   <=>   FE( ML(A,B) * ML(-acc, gamma) * ML(-C, delta) ) == alpha_beta
+    G1Affine accA = acc.to_affine();
+    Fq12 f = Fq12::one();
+    auto ml = [&](const G1Affine &P, const G2Affine &Q) { if (!P.is_inf() && !Q.is_inf()) f = f * pairing::miller_loop(P, Q); };
+    ml(pA, pB); ml(accA.neg(), gamma_g2); ml(pC.neg(), delta_g2);
+    return pairing::final_exponentiation(f) == alpha_beta ? 0 : 1;
+}
+
+// bilinearity probe for the tests: writes e(a*G1, b*G2) (384 B) for canonical scalars a, b
+int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]) {
+    uint32_t ea[8], eb[8]; memcpy(ea, a, 32); memcpy(eb, b, 32);
+    G1Affine P = G1::from_affine(g1_generator()).mul(ea, 8).to_affine();
+    G2Affine Q = G2::from_affine(g2_generator()).mul(eb, 8).to_affine();
+    ser::put_fq12(out, pairing::reduced_pairing(P, Q));
+    return 0;
+}
+
+}  // extern "C"
