@@ -76,66 +76,62 @@ def extras(zkg, torch, args, with_cpu):
     out["ntt_2p20"] = {"ms_per_transform": round(dt * 1e3, 4), "GBps_algorithmic": round(64 * n / dt / 1e9, 2), "bytes_per_element": 64,
                        "frac_of_hbm_peak": round(64 * n / dt / 1e9 / HBM_PEAK_GBPS, 5), "forward_inverse_roundtrip_exact": roundtrip_ok}
 
-    # ---- Groth16 prove, m = 2^logm, synthetic zklaim-shaped R1CS, synthetic CRS (queries = k_i*G built on device)
-    from zklaim_amd import synth
+    # ---- Groth16 prove on zklaim's own credential circuit (zklaim_gadget rebuilt on the host, zklaim_amd/csrc/zklaim_circuit.hip):
+    #      k payloads -> m = 2^logm (k = 8 -> 2^18, BASELINE configs[3]; k = 20 -> 2^20, the north-star size).  Keys come from the
+    #      product's GPU generator with a fixed trapdoor; (r, s) fixed; the CPU oracle proves the same instance for byte parity.
     logm = args.prove_logm
+    k_payloads = {15: 1, 16: 2, 18: 8, 20: 20}.get(logm, 8)
     t_syn = time.perf_counter()
-    nv, l, A, B, C, w = synth.zklaim_shaped(logm, num_inputs=41, seed=4)
-    m = 1 << logm
-
-    def g1_points(cnt, seed):
-        ks = splitmix_fr(cnt, seed); d_k = torch.from_numpy(ks.view(np.int64)).cuda()
-        o = torch.empty((cnt, 8), dtype=torch.int64, device="cuda")
-        zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), cnt, o.data_ptr()); torch.cuda.synchronize()
-        return o.cpu().numpy().view(np.uint64)
-
-    def g2_points(cnt, seed):
-        ks = splitmix_fr(cnt, seed); d_k = torch.from_numpy(ks.view(np.int64)).cuda()
-        o = torch.empty((cnt, 16), dtype=torch.int64, device="cuda")
-        zkg.fixed_base_g2_dev(G2_GEN_MONT, d_k.data_ptr(), cnt, o.data_ptr()); torch.cuda.synchronize()
-        return o.cpu().numpy().view(np.uint64)
-
-    small1 = g1_points(3, SEED + 0x40); small2 = g2_points(2, SEED + 0x41)
-    arrays = dict(alpha_g1=small1[0], beta_g1=small1[1], delta_g1=small1[2], beta_g2=small2[0], delta_g2=small2[1],
-                  A_query=g1_points(nv + 1, SEED + 0x42), B_g1=g1_points(nv + 1, SEED + 0x43), B_g2=g2_points(nv + 1, SEED + 0x44),
-                  H_query=g1_points(m - 1, SEED + 0x45), L_query=g1_points(nv - l, SEED + 0x46))
     keep = []
-    cs = zkg.make_r1cs(nv, l, A, B, C, keep)
-    pk = zkg.make_pk(cs, arrays, logm, keep)
-    crs = zkg.Crs(pk)
+    pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i)
+           for i in range(k_payloads)]
+    ctx = zkg.make_ctx(pls, keep)
+    ck = zkg.ZklaimCircuit(ctx)
+    assert ck.is_satisfied()
+    nv, l, ncons = ck.r1cs.num_variables, ck.r1cs.num_inputs, ck.r1cs.num_constraints
+    w = ck.witness()
+    kp = zkg.Keypair(ck.r1cs, splitmix_fr(5, SEED + 4))
+    m = 1 << kp.pk.log_m
+    logm = kp.pk.log_m
+    t_setup = time.perf_counter() - t_syn
+    crs = zkg.Crs(kp.pk)
     rs = splitmix_fr(2, SEED + 5)
-    setup_s = time.perf_counter() - t_syn
     rc, proof = crs.prove(w, rs[0], rs[1])
-    assert rc == 0, "synthetic system must be satisfiable"
-    reps = 5
+    assert rc == 0, "credential must satisfy the circuit"
+    verified = zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
+    reps = 10
     t0 = time.perf_counter()
     for _ in range(reps):
         rc, proof2 = crs.prove(w, rs[0], rs[1])
     dt = (time.perf_counter() - t0) / reps
+    A, B, C = ck.csr()
     nnz = int(len(A[1]) + len(B[1]) + len(C[1]))
     alg_bytes = 7 * 64 * m + 96 * (nv + 1) + (128 + 64 + 32) * (nv + 1) + 96 * (m - 1) + 96 * (nv - l)
-    g = {"log_m": logm, "num_variables": int(nv), "num_inputs": int(l), "num_constraints": int(m - l - 1), "nnz": nnz,
-         "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3), "algorithmic_bytes_per_proof": int(alg_bytes),
-         "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
+    g = {"circuit": f"zklaim_gadget, {k_payloads} payloads (SHA-256 + 5 comparisons each)", "log_m": logm, "num_variables": int(nv), "num_inputs": int(l),
+         "num_constraints": int(ncons), "nnz": nnz, "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3),
+         "algorithmic_bytes_per_proof": int(alg_bytes), "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
          "stage_names": ["r1cs_matvec", "7_ntt+pointwise", "msm_A", "msm_B_g1", "msm_B_g2", "msm_H", "msm_L", "wall_total_incl_host_assembly"],
          "stage_note": "the five MSMs run concurrently on separate HIP streams; their times overlap",
-         "setup_seconds_excluded": round(setup_s, 1), "deterministic": proof2 == proof,
-         "crs": "synthetic: query points k_i*G from SplitMix64 scalars (timing and GPU-vs-CPU byte parity do not need a trapdoor-consistent CRS)"}
+         "trusted_setup_seconds_gpu": round(t_setup, 2), "deterministic": proof2 == proof, "proof_verifies": verified}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import zkoracle
         okeep = []
+        if kp.swapped:
+            A, B = B, A
         ocs = zkoracle.make_r1cs(nv, l, A, B, C, okeep)
+        arrays = {name: kp.array(name, cnt, lim) for name, cnt, lim in (("A_query", nv + 1, 8), ("B_g1", nv + 1, 8), ("B_g2", nv + 1, 16), ("H_query", m - 1, 8),
+                  ("L_query", nv - l, 8), ("alpha_g1", 1, 8), ("beta_g1", 1, 8), ("delta_g1", 1, 8), ("beta_g2", 1, 16), ("delta_g2", 1, 16))}
         arrays["m"] = m
         opk = zkoracle.make_pk(ocs, arrays)
         t1 = time.perf_counter()
         rc_o, proof_o = zkoracle.groth16_prove(opk, w, rs[0], rs[1], True, 1)
         cpu_dt = time.perf_counter() - t1
         g["cpu_baseline"] = {"proofs_per_sec": round(1.0 / cpu_dt, 4), "seconds": round(cpu_dt, 2), "cores": 1, "kind": "port",
-                             "sample": "one full prove of the same system, oracle restatement of r1cs_gg_ppzksnark_prover, single thread"}
+                             "sample": "one full prove of the same credential, oracle restatement of r1cs_gg_ppzksnark_prover, single thread"}
         g["proof_bytes_match_cpu"] = bool(rc_o == 0 and proof_o == proof)
         g["speedup_vs_cpu_1core"] = round(cpu_dt / dt, 1)
-    crs.free()
+    crs.free(); kp.free(); ck.free()
     out["groth16_prove"] = g
     return out
 
@@ -148,7 +144,7 @@ def main():
     ap.add_argument("--logn", type=int, default=LOGN, help="log2 points per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
-    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg (BASELINE configs[3])")
+    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 20 payloads")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print banners (RCCL prints its version on first use) go to stderr

@@ -152,6 +152,8 @@ int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
 struct zklaim_ctx;
 typedef struct zkg_circuit zkg_circuit;
 zkg_circuit *zkg_zklaim_circuit_new(const struct zklaim_ctx *ctx, int with_witness);
+zkg_circuit *zkg_zklaim_witness_new(const struct zklaim_ctx *ctx);   /* witness only: no constraints, no CSR (prover with a resident key) */
+uint32_t zkg_circuit_num_variables(const zkg_circuit *c);
 void zkg_circuit_free(zkg_circuit *c);
 int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out);        /* pointers stay valid until zkg_circuit_free            */
 const uint64_t *zkg_circuit_witness(const zkg_circuit *c);        /* num_variables x 4 limbs (NULL without witness)        */

@@ -36,6 +36,9 @@ def test_single_payload_satisfied_and_shapes(oracle):
     assert (ck0.r1cs.num_variables, ck0.r1cs.num_inputs, ck0.r1cs.num_constraints) == (n, l, C)
     for (r0, c0, v0), (r1, c1, v1) in zip(ck0.csr(), ck.csr()):
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1) and np.array_equal(v0, v1)
+    # the witness-only pass (what libsnark_prove uses with a resident key) numbers and assigns the variables identically
+    wo = zkg.ZklaimCircuit(ctx, witness_only=True)
+    assert wo.r1cs.num_variables == n and np.array_equal(wo.witness(), w)
     print("zklaim k=1: variables", n, "constraints", C)
 
 

@@ -1,0 +1,31 @@
+"""The reference's own benchmark sweep (zklaim/main_benchmark.c:34-172,175-182) through the drop-in seam: for k payloads, time
+libsnark_trusted_setup ("issuer"), libsnark_prove ("prover") and libsnark_verify ("verifier") on a zklaim_ctx and record the
+pk / vk / proof sizes — same CSV columns as the reference writes (main_benchmark.c:158-165), but WALL-CLOCK milliseconds: the
+reference's CLOCK_THREAD_CPUTIME_ID (main_benchmark.c:113-117) does not see time spent waiting on the GPU.
+Usage: python tools/zklaim_benchmark.py [k ...]   (default 1 2 4 8 16 20; RUNS=3 instead of the reference's 30)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import zklaim_amd as zkg
+
+ks = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8, 16, 20]
+RUNS = 3
+zkg.init(0)
+print("time,k,issuer_ms,prover_ms,verifier_ms,pk_B,vk_B,proof_B,constraints,first_prove_ms_incl_key_upload")
+for k in ks:
+    for run in range(RUNS):
+        keep = []
+        pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i + run)
+               for i in range(k)]
+        ctx = zkg.make_ctx(pls, keep)
+        t0 = time.perf_counter(); rc = zkg.libsnark_trusted_setup(ctx); t_issuer = time.perf_counter() - t0
+        assert rc == 0
+        t0 = time.perf_counter(); rc = zkg.libsnark_prove(ctx); t_first = time.perf_counter() - t0      # includes pk blob parse + GPU decompression + upload
+        assert rc == 0
+        t0 = time.perf_counter(); rc = zkg.libsnark_prove(ctx); t_prover = time.perf_counter() - t0     # resident key
+        assert rc == 0
+        t0 = time.perf_counter(); rc = zkg.libsnark_verify(ctx); t_verifier = time.perf_counter() - t0
+        assert rc == 0
+        ncons = zkg.ZklaimCircuit(ctx, with_witness=False).r1cs.num_constraints
+        print(f"{int(time.time())},{k},{t_issuer*1e3:.1f},{t_prover*1e3:.2f},{t_verifier*1e3:.2f},{ctx.pk_size},{ctx.vk_size},{ctx.proof_size},{ncons},{t_first*1e3:.1f}", flush=True)
+        zkg.lib().zkg_compat_reset()

@@ -16,7 +16,7 @@ DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
-    "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
+    "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe",
     "zkg_compat_reset",
@@ -285,20 +285,29 @@ def make_ctx(payloads, keep):
 class ZklaimCircuit:
     """R1CS (+ witness) of zklaim_gadget for a zklaim_ctx, built on the host by libzkg.so"""
 
-    def __init__(self, ctx, with_witness=True):
+    def __init__(self, ctx, with_witness=True, witness_only=False):
         L = lib()
         L.zkg_zklaim_circuit_new.restype = C.c_void_p
         L.zkg_zklaim_circuit_new.argtypes = [C.c_void_p, C.c_int]
+        L.zkg_zklaim_witness_new.restype = C.c_void_p
+        L.zkg_zklaim_witness_new.argtypes = [C.c_void_p]
+        L.zkg_circuit_num_variables.restype = C.c_uint32
+        L.zkg_circuit_num_variables.argtypes = [C.c_void_p]
         L.zkg_circuit_witness.restype = C.c_void_p
         L.zkg_circuit_first_unsatisfied.restype = C.c_long
         for f in (L.zkg_circuit_free, L.zkg_circuit_witness, L.zkg_circuit_is_satisfied, L.zkg_circuit_first_unsatisfied):
             f.argtypes = [C.c_void_p]
         L.zkg_circuit_r1cs.argtypes = [C.c_void_p, C.c_void_p]
-        self._h = L.zkg_zklaim_circuit_new(C.cast(C.pointer(ctx), C.c_void_p), int(with_witness))
+        if witness_only:
+            self._h = L.zkg_zklaim_witness_new(C.cast(C.pointer(ctx), C.c_void_p))
+        else:
+            self._h = L.zkg_zklaim_circuit_new(C.cast(C.pointer(ctx), C.c_void_p), int(with_witness))
         if not self._h:
             raise ZkgError("zkg_zklaim_circuit_new failed: " + L.zkg_last_error().decode())
         self.r1cs = R1CS()
         _check(L.zkg_circuit_r1cs(self._h, C.byref(self.r1cs)), "zkg_circuit_r1cs")
+        if witness_only:
+            self.r1cs.num_variables = L.zkg_circuit_num_variables(self._h)
         self.with_witness = with_witness
 
     def witness(self):

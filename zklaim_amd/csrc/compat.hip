@@ -20,6 +20,7 @@ using namespace zk;
 
 extern "C" {
 struct zkg_keypair;
+zkg_circuit *zkg_zklaim_witness_new(const zklaim_ctx *ctx);
 zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor);
 void zkg_keypair_free(zkg_keypair *kp);
 size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
@@ -41,9 +42,15 @@ int ensure_init() {
     g_inited = true;
     return 0;
 }
-uint64_t digest(const unsigned char *p, size_t n) {            // FNV-1a over the whole blob (~1 GB/s; the blob is read once anyway)
+uint64_t digest(const unsigned char *p, size_t n) {            // FNV-1a over the head, the tail and 256 strided 4 KiB pages of the blob
     uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    auto eat = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi && i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } };
+    if (n <= (1u << 21)) eat(0, n);
+    else {
+        eat(0, 1 << 16); eat(n - (1 << 16), n);
+        size_t step = n / 256;
+        for (size_t k = 1; k < 256; ++k) eat(k * step, k * step + 4096);
+    }
     return h ^ n;
 }
 void random_fr_mont(uint64_t out[4]) {
@@ -96,19 +103,18 @@ int libsnark_prove(zklaim_ctx *ctx) {
         if (g_crs_cache.size() >= 4) { for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs); g_crs_cache.clear(); }
         g_crs_cache[d] = {d, ctx->pk_size, crs};
     }
-    zkg_circuit *ck = zkg_zklaim_circuit_new(ctx, 1);             // gadget + constraints + witness (snark.cpp:113-118)
+    // the witness only: the constraint system already sits on the GPU inside the resident key, and pb.is_satisfied()
+    // (snark.cpp:121-124) is evaluated there, fused with the R1CS mat-vec of the prover (check_satisfied = 1)
+    zkg_circuit *ck = zkg_zklaim_witness_new(ctx);
     if (!ck) return ZKLAIM_ERROR;
     int rc = ZKLAIM_ERROR;
-    if (!zkg_circuit_is_satisfied(ck)) rc = 1;                    // "system not satisfied!! not creating proof." (snark.cpp:121-124)
-    else {
-        uint64_t r[4], s[4];
-        random_fr_mont(r); random_fr_mont(s);
-        unsigned char *proof = (unsigned char *)malloc(ZKG_PROOF_BYTES);
-        size_t len = 0;
-        int prc = proof ? zkg_groth16_prove(crs, zkg_circuit_witness(ck), r, s, 0, proof, &len) : ZKG_ERROR;
-        if (prc == ZKG_OK) { ctx->proof = proof; ctx->proof_size = len; rc = ZKLAIM_OK; }      // libsnark_wrapper.cpp:242
-        else free(proof);
-    }
+    uint64_t r[4], s[4];
+    random_fr_mont(r); random_fr_mont(s);
+    unsigned char *proof = (unsigned char *)malloc(ZKG_PROOF_BYTES);
+    size_t len = 0;
+    int prc = proof ? zkg_groth16_prove(crs, zkg_circuit_witness(ck), r, s, 1, proof, &len) : ZKG_ERROR;
+    if (prc == ZKG_OK) { ctx->proof = proof; ctx->proof_size = len; rc = ZKLAIM_OK; }          // libsnark_wrapper.cpp:242
+    else { free(proof); if (prc == ZKG_UNSATISFIED && strstr(zkg_last_error(), "not satisfied")) rc = 1; }   // "system not satisfied!! not creating proof."
     zkg_circuit_free(ck);
     return rc;
 }

@@ -32,14 +32,14 @@ inline Bit bit_xor(Builder &pb, Bit a, Bit b) {
     if (a.is_const()) return a.konst ? !b : b;
     if (b.is_const()) return b.konst ? !a : a;
     Bit r = new_bit(pb, a.value(pb) != b.value(pb));
-    pb.enforce(a.lc() * 2, b.lc(), a.lc() + b.lc() - r.lc());                 // 2ab = a + b - r
+    if (pb.recording) pb.enforce(a.lc() * 2, b.lc(), a.lc() + b.lc() - r.lc());                 // 2ab = a + b - r
     return r;
 }
 inline Bit bit_and(Builder &pb, Bit a, Bit b) {
     if (a.is_const()) return a.konst ? b : Bit::zero();
     if (b.is_const()) return b.konst ? a : Bit::zero();
     Bit r = new_bit(pb, a.value(pb) && b.value(pb));
-    pb.enforce(a.lc(), b.lc(), r.lc());
+    if (pb.recording) pb.enforce(a.lc(), b.lc(), r.lc());
     return r;
 }
 inline Bit bit_or(Builder &pb, Bit a, Bit b) { return !bit_and(pb, !a, !b); }
@@ -49,7 +49,7 @@ inline Bit bit_choice(Builder &pb, Bit e, Bit f, Bit g) {
     if (e.is_const()) return e.konst ? f : g;
     if (f.is_const() && g.is_const()) { if (f.konst == g.konst) return f; return f.konst ? e : !e; }
     Bit r = new_bit(pb, e.value(pb) ? f.value(pb) : g.value(pb));
-    pb.enforce(e.lc(), f.lc() - g.lc(), r.lc() - g.lc());                     // e (f - g) = r - g
+    if (pb.recording) pb.enforce(e.lc(), f.lc() - g.lc(), r.lc() - g.lc());                     // e (f - g) = r - g
     return r;
 }
 inline Bit bit_majority(Builder &pb, Bit a, Bit b, Bit c) {
@@ -59,7 +59,7 @@ inline Bit bit_majority(Builder &pb, Bit a, Bit b, Bit c) {
     Bit t = bit_and(pb, a, b);
     int s = (int)a.value(pb) + (int)b.value(pb) + (int)c.value(pb);
     Bit r = new_bit(pb, s >= 2);
-    pb.enforce(c.lc(), a.lc() + b.lc() - t.lc() * 2, r.lc() - t.lc());         // r = ab + c (a + b - 2ab)
+    if (pb.recording) pb.enforce(c.lc(), a.lc() + b.lc() - t.lc() * 2, r.lc() - t.lc());         // r = ab + c (a + b - 2ab)
     return r;
 }
 
@@ -78,22 +78,24 @@ inline Word word_xor3(Builder &pb, const Word &a, const Word &b, const Word &c) 
 inline Word add_mod32(Builder &pb, const std::vector<Word> &terms, uint32_t konst, const Var *out = nullptr) {
     bool all_const = true;
     for (auto &w : terms) for (auto &b : w) all_const = all_const && b.is_const();
-    uint64_t sum = konst; LC s = LC::constant((uint64_t)konst);
-    for (auto &w : terms) { sum += word_value(pb, w); s = s + word_lc(w); }
+    uint64_t sum = konst; LC s;
+    for (auto &w : terms) sum += word_value(pb, w);
     if (all_const && !out) return word_const((uint32_t)sum);
+    const bool rec = pb.recording;
+    if (rec) { s = LC::constant((uint64_t)konst); for (auto &w : terms) s = s + word_lc(w); }
     int extra = 0; while (((uint64_t)(terms.size() + 1) << 32) > ((uint64_t)1 << (32 + extra))) ++extra;   // enough carry bits for the worst case
     Word r; LC packed;
     for (int i = 0; i < 32; ++i) {                                             // weight 2^(31-i)
         bool bv = (sum >> (31 - i)) & 1;
         if (out) { r[i] = Bit::var(out[i]); }
         else { r[i] = new_bit(pb, bv); pb.enforce_boolean(r[i].v); }
-        packed = packed + r[i].lc() * ((uint64_t)1 << (31 - i));
+        if (rec) packed = packed + r[i].lc() * ((uint64_t)1 << (31 - i));
     }
     for (int j = 0; j < extra; ++j) {
         Bit c = new_bit(pb, (sum >> (32 + j)) & 1); pb.enforce_boolean(c.v);
-        packed = packed + c.lc() * ((uint64_t)1 << (32 + j));
+        if (rec) packed = packed + c.lc() * ((uint64_t)1 << (32 + j));
     }
-    pb.enforce(LC::constant(1), s, packed);
+    if (rec) pb.enforce(LC::constant(1), s, packed);
     return r;
 }
 
@@ -135,6 +137,7 @@ inline void sha256_compress_from_iv(Builder &pb, const std::vector<Bit> &block /
 
 // packing: 1 * sum_i 2^i bits[i] = packed      (libsnark packing_gadget; little-endian over the given order)
 inline void enforce_packing(Builder &pb, const std::vector<Var> &bits, size_t lo, size_t hi, Var packed, bool enforce_bitness) {
+    if (!pb.recording) return;
     LC s; Fr w = Fr::one();
     for (size_t i = lo; i < hi; ++i) { if (enforce_bitness) pb.enforce_boolean(bits[i]); s.add(bits[i], w); w = w.dbl(); }
     pb.enforce(LC::constant(1), s, LC(packed));
@@ -154,6 +157,7 @@ inline Comparison comparison_alloc(Builder &pb, size_t n, Var less_or_eq) {
     return c;
 }
 inline void comparison_constraints(Builder &pb, const Comparison &c, size_t n, Var A, Var B, Var less, Var less_or_eq) {
+    if (!pb.recording) return;
     enforce_packing(pb, c.alpha, 0, n + 1, c.alpha_packed, true);
     Fr two_n = Fr::one(); for (size_t i = 0; i < n; ++i) two_n = two_n.dbl();
     pb.enforce(LC::constant(1), LC::constant(two_n) + LC(B) - LC(A), LC(c.alpha_packed));

@@ -33,13 +33,14 @@ struct Builder {
     std::vector<Fr> val;                 // val[0] == 1
     std::vector<Constraint> cons;
     uint32_t num_inputs = 0;
+    bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
     Builder() { val.push_back(Fr::one()); }
     Var alloc() { val.push_back(Fr::zero()); return (Var)(val.size() - 1); }
     std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
     void set_input_sizes(uint32_t n) { num_inputs = n; }
     uint32_t num_variables() const { return (uint32_t)val.size() - 1; }
-    void enforce(const LC &a, const LC &b, const LC &c) { cons.push_back({a, b, c}); }
-    void enforce_boolean(Var v) { enforce(LC(v), LC::constant(1) - LC(v), LC()); }          // v (1 - v) = 0
+    void enforce(const LC &a, const LC &b, const LC &c) { if (recording) cons.push_back({a, b, c}); }
+    void enforce_boolean(Var v) { if (recording) enforce(LC(v), LC::constant(1) - LC(v), LC()); }          // v (1 - v) = 0
     Fr eval(const LC &l) const { Fr s = Fr::zero(); for (auto &e : l.t) s += e.second * val[e.first]; return s; }
     bool is_satisfied() const { for (auto &c : cons) if (eval(c.a) * eval(c.b) != eval(c.c)) return false; return true; }
     size_t first_unsatisfied() const { for (size_t i = 0; i < cons.size(); ++i) if (eval(cons[i].a) * eval(cons[i].b) != eval(cons[i].c)) return i; return (size_t)-1; }

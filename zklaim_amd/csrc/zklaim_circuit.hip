@@ -57,9 +57,10 @@ struct zkg_circuit {
     bool has_witness = false;
 };
 
-static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness) {
+static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool witness_only = false) {
     zkg_circuit *ck = new zkg_circuit();
     Builder &pb = ck->pb;
+    pb.recording = !witness_only;                           // proving: the resident key already holds the constraint system
     const size_t k = ctx->num_of_payloads;
     const bool bind_packings = getenv("ZKG_BIND_PACKINGS") != nullptr;
     std::vector<const zklaim_payload *> pls;
@@ -128,7 +129,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness) {
             comparison_constraints(pb, cmp, 64, data[i][j], refvals[j + 8 * i], less[i][j], leq[i][j]);
             if (with_witness) comparison_witness(pb, cmp, 64, attr[i][j], refv[i][j], less[i][j], leq[i][j]);
         }
-        for (int j = 0; j < 5; ++j) {                                           // op selection: op * relation = op
+        if (pb.recording) for (int j = 0; j < 5; ++j) {                                           // op selection: op * relation = op
             auto op = [&](int o) { return LC(opsvals[o + j * 8 + i * 64]); };
             LC L(less[i][j]), E(leq[i][j]), one = LC::constant(1);
             pb.enforce(op(0), L, op(0));                                        // <
@@ -140,7 +141,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness) {
             pb.enforce(op(5), L + (one - E), op(5));                            // !=
             pb.enforce(op(6), one, op(6));                                      // noop
         }
-        for (int j = 0; j < 5; ++j) {                                           // exactly one op per attribute
+        if (pb.recording) for (int j = 0; j < 5; ++j) {                                           // exactly one op per attribute
             LC s; for (int o = 0; o < 7; ++o) s = s + LC(opsvals[o + j * 8 + i * 64]);
             pb.enforce(LC::constant(1), s, LC::constant(1));
         }
@@ -153,7 +154,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness) {
         block[512 - 9] = Bit::one(); block[512 - 8] = Bit::one();              // length 384 = 0x0180, big-endian in the last 64 bits
         sha256_compress_from_iv(pb, block, h_bits[i]);
     }
-    pb.export_csr(ck->A, ck->B, ck->C);
+    if (pb.recording) pb.export_csr(ck->A, ck->B, ck->C);
     if (with_witness) {
         ck->has_witness = true;
         ck->witness.resize((size_t)pb.num_variables() * 4);
@@ -168,6 +169,11 @@ zkg_circuit *zkg_zklaim_circuit_new(const zklaim_ctx *ctx, int with_witness) {
     if (!ctx) { set_error("zkg_zklaim_circuit_new: null ctx"); return nullptr; }
     return build_zklaim(ctx, with_witness != 0);
 }
+// witness only (generate_r1cs_witness without re-deriving the constraints): what a prover holding a resident key needs
+zkg_circuit *zkg_zklaim_witness_new(const zklaim_ctx *ctx) {
+    if (!ctx) { set_error("zkg_zklaim_witness_new: null ctx"); return nullptr; }
+    return build_zklaim(ctx, true, true);
+}
 void zkg_circuit_free(zkg_circuit *c) { delete c; }
 
 int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
@@ -180,7 +186,8 @@ int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
     return ZKG_OK;
 }
 const uint64_t *zkg_circuit_witness(const zkg_circuit *c) { return (c && c->has_witness) ? c->witness.data() : nullptr; }
-int zkg_circuit_is_satisfied(const zkg_circuit *c) { return c && c->has_witness && c->pb.is_satisfied() ? 1 : 0; }
+int zkg_circuit_is_satisfied(const zkg_circuit *c) { return c && c->has_witness && c->pb.recording && c->pb.is_satisfied() ? 1 : 0; }
+uint32_t zkg_circuit_num_variables(const zkg_circuit *c) { return c ? c->pb.num_variables() : 0; }
 long zkg_circuit_first_unsatisfied(const zkg_circuit *c) { return c ? (long)c->pb.first_unsatisfied() : -2; }
 
 // zklaim_input_map (zklaim_gadget.cpp:115-150): hash || refs(512 b) || ops(512 b) per payload, 253 bits per field element
