@@ -106,3 +106,18 @@ def test_payload_counts(zkg, k):
     ctx, keep = run_flow(zkg, pls)
     assert zkg.libsnark_verify(ctx) == 0
     zkg.lib().zkg_compat_reset()
+
+
+def test_c_caller_links_the_seam(zkg, tmp_path):
+    """a plain C program (gcc) calling libsnark_trusted_setup / prove / verify in libzkg.so, as zklaim.c does"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "seam_demo")
+    so_dir = os.path.join(root, "zklaim_amd")
+    cmd = ["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "seam_demo.c"), "-o", exe,
+           os.path.join(so_dir, "libzkg.so"), "-lcrypto", "-Wl,-rpath," + so_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr[-500:])
+    assert out.returncode == 0 and "seam demo ok" in out.stdout
