@@ -24,8 +24,6 @@ static constexpr int NTT_MAX_R = 8;
 
 struct alignas(16) U4 { uint32_t a, b, c, d; };
 
-ZK_D Fr ld_fr(const Fr *p) { return *p; }
-
 struct NttPassArgs {
     const Fr *src; Fr *dst; const Fr *tw; const Fr *pre; const Fr *post;
     Fr post_scalar;
@@ -40,10 +38,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
     const uint32_t s1 = A.s0 + A.R;
     const uint32_t lo_mask = (1u << A.s0) - 1;
-    auto lds = [&](uint32_t row, uint32_t c) -> Fr * { return reinterpret_cast<Fr *>(&smem[row * stride + 2 * c]); };
     auto lds_ld = [&](uint32_t row, uint32_t c) { Fr r; const U4 *p = &smem[row * stride + 2 * c]; *reinterpret_cast<U4 *>(&r.v[0]) = p[0]; *reinterpret_cast<U4 *>(&r.v[4]) = p[1]; return r; };
     auto lds_st = [&](uint32_t row, uint32_t c, const Fr &r) { U4 *p = &smem[row * stride + 2 * c]; p[0] = *reinterpret_cast<const U4 *>(&r.v[0]); p[1] = *reinterpret_cast<const U4 *>(&r.v[4]); };
-    (void)lds;
 
     // ---- load tile (c fastest: CW*32 B contiguous per row)
     for (uint32_t e = tid; e < rows * CW; e += NTT_THREADS) {
@@ -94,11 +90,6 @@ __global__ void k_powers(Fr *out, size_t n, Fr base, Fr scale) {
     if (i0 >= n) return;
     Fr cur = scale * base.pow_u64(i0);
     for (size_t i = i0; i < i0 + 64 && i < n; ++i) { out[i] = cur.normalized(); cur = cur * base; }
-}
-
-__global__ void k_scale(Fr *a, size_t n, Fr s) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = (a[i] * s).normalized();
 }
 
 int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s) {

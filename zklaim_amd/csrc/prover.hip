@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace zk {
 
@@ -32,6 +33,7 @@ struct zkg_crs {
     zk::NttDomain *dom = nullptr;
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
     zk::DevBuf z, aA, aB, aC, flag;             // [1 | w] and the three evaluation vectors
+    zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
     zk::DevBuf ntt_scratch[3];                  // this CRS's own inter-pass vectors (one per concurrent transform chain)
     hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
@@ -44,24 +46,59 @@ struct zkg_crs {
 
 namespace zk {
 
-// one lane per constraint row: <A_i,z>, <B_i,z>, <C_i,z>; rows C..C+l of aA carry the input-consistency
-// terms (r1cs_to_qap_witness_map); flag |= 1 when a row violates <A,z><B,z> = <C,z> (snark.cpp:121-124)
+// <A_i,z>, <B_i,z>, <C_i,z> for every constraint row.  Rows are short (1-3 terms) except packing and 32-bit-addition rows
+// (up to 253 terms): a lane walking such a row alone would set the latency of the whole stage, so rows longer than
+// LONG_ROW terms are left to k_r1cs_long (one wavefront per row, lanes stride over the terms, shuffle reduction).
+// Rows C..C+l of aA carry the input-consistency terms (r1cs_to_qap_witness_map).
+static constexpr uint32_t LONG_ROW = 24;
+
+ZK_D Fr row_dot_short(const uint32_t *rp, const uint32_t *col, const Fr *val, const Fr *z, size_t i) {
+    Fr acc = Fr::zero();
+    uint32_t k = rp[i], e = rp[i + 1];
+    if (e - k > LONG_ROW) return acc;                      // filled in by k_r1cs_long
+    for (; k < e; ++k) acc += val[k] * z[col[k]];
+    return acc;
+}
 __global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
                                                     const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
                                                     const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
-                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, uint32_t *flag) {
+                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
     if (i < C) {
-        for (uint32_t k = a_rp[i]; k < a_rp[i + 1]; ++k) a += a_val[k] * z[a_col[k]];
-        for (uint32_t k = b_rp[i]; k < b_rp[i + 1]; ++k) b += b_val[k] * z[b_col[k]];
-        for (uint32_t k = c_rp[i]; k < c_rp[i + 1]; ++k) c += c_val[k] * z[c_col[k]];
-        if (a * b != c) atomicOr(flag, 1u);
+        a = row_dot_short(a_rp, a_col, a_val, z, i);
+        b = row_dot_short(b_rp, b_col, b_val, z, i);
+        c = row_dot_short(c_rp, c_col, c_val, z, i);
     } else if (i <= (size_t)C + l) {
         a = z[i - C];
     }
     aA[i] = a.normalized(); aB[i] = b.normalized(); aC[i] = c.normalized();
+}
+// long rows: entry = (matrix << 30) | row; one wavefront each
+__global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_t n_long,
+                                                    const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
+                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
+                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
+                                                    const Fr *z, Fr *aA, Fr *aB, Fr *aC) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_long) return;
+    uint32_t e = list[wave], mtx = e >> 30, row = e & 0x3fffffffu;
+    const uint32_t *rp = mtx == 0 ? a_rp : mtx == 1 ? b_rp : c_rp, *col = mtx == 0 ? a_col : mtx == 1 ? b_col : c_col;
+    const Fr *val = mtx == 0 ? a_val : mtx == 1 ? b_val : c_val;
+    Fr acc = Fr::zero();
+    for (uint32_t k = rp[row] + lane; k < rp[row + 1]; k += 64) acc += val[k] * z[col[k]];
+    for (int d = 32; d >= 1; d >>= 1) {
+        Fr o;
+        for (int j = 0; j < 8; ++j) o.v[j] = __shfl_xor(acc.v[j], d, 64);
+        acc += o;
+    }
+    if (lane == 0) (mtx == 0 ? aA : mtx == 1 ? aB : aC)[row] = acc.normalized();
+}
+// flag |= 1 when a row violates <A,z><B,z> = <C,z>: the pb.is_satisfied() gate of snark.cpp:121-124
+__global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, const Fr *aC, uint32_t C, uint32_t *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C && aA[i] * aB[i] != aC[i]) atomicOr(flag, 1u);
 }
 
 __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one(); }
@@ -112,8 +149,16 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                        crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(),
-                       z, crs->C, crs->l, m, aA, aB, aC, crs->flag.as<uint32_t>());
-    if (want_flag) ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
+                       z, crs->C, crs->l, m, aA, aB, aC);
+    if (crs->n_long)
+        hipLaunchKernelGGL(k_r1cs_long, dim3((crs->n_long + 3) / 4), dim3(256), 0, s, crs->long_rows.as<uint32_t>(), crs->n_long,
+                           crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
+                           crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
+                           crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(), z, aA, aB, aC);
+    if (want_flag) {
+        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, crs->flag.as<uint32_t>());
+        ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
+    }
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
     // iFFT then cosetFFT for each of aA, aB, aC — three independent chains, run concurrently (a 2^18 transform fills half the
     // chip): inverse transform with the fused post table g^i/m, then a plain forward transform
@@ -155,6 +200,14 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     ok = ok && upload(crs->A_query, pk->A_query, (n + 1) * 64) == 0 && upload(crs->B_g1, pk->B_g1, (n + 1) * 64) == 0 &&
          upload(crs->B_g2, pk->B_g2, (n + 1) * 128) == 0 && upload(crs->H_query, pk->H_query, (m - 1) * 64) == 0 &&
          upload(crs->L_query, pk->L_query, (n - l) * 64) == 0;
+    if (ok) {                                                                // rows left to the wavefront-per-row kernel
+        std::vector<uint32_t> lr;
+        const uint32_t *rps[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr};
+        for (uint32_t mtx = 0; mtx < 3; ++mtx)
+            for (uint32_t r = 0; r < crs->C; ++r) if (rps[mtx][r + 1] - rps[mtx][r] > LONG_ROW) lr.push_back((mtx << 30) | r);
+        crs->n_long = (uint32_t)lr.size();
+        ok = crs->C < (1u << 30) && upload(crs->long_rows, lr.data(), lr.size() * 4) == 0;
+    }
     if (ok) {
         memcpy(&crs->alpha_g1, pk->alpha_g1, 64); memcpy(&crs->beta_g1, pk->beta_g1, 64); memcpy(&crs->delta_g1, pk->delta_g1, 64);
         memcpy(&crs->beta_g2, pk->beta_g2, 128); memcpy(&crs->delta_g2, pk->delta_g2, 128);
@@ -191,7 +244,7 @@ void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
                       &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag,
-                      &crs->ntt_scratch[0], &crs->ntt_scratch[1], &crs->ntt_scratch[2]})
+                      &crs->ntt_scratch[0], &crs->ntt_scratch[1], &crs->ntt_scratch[2], &crs->long_rows})
         b->release();
     msm_job_destroy(crs->job_a); msm_job_destroy(crs->job_b1); msm_job_destroy(crs->job_b2); msm_job_destroy(crs->job_h); msm_job_destroy(crs->job_l);
     if (crs->stream) (void)hipStreamDestroy(crs->stream);
