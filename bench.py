@@ -96,7 +96,8 @@ def extras(zkg, torch, args, with_cpu):
     t_setup = time.perf_counter() - t_syn
     crs = zkg.Crs(kp.pk)
     rs = splitmix_fr(2, SEED + 5)
-    rc, proof = crs.prove(w, rs[0], rs[1])
+    for _ in range(4):                      # the first calls grow the runtime's per-stream pools (9 streams in flight); steady state after ~3
+        rc, proof = crs.prove(w, rs[0], rs[1])
     assert rc == 0, "credential must satisfy the circuit"
     verified = zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
     reps = 10

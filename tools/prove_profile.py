@@ -21,5 +21,5 @@ arrays = dict(alpha_g1=s1[0], beta_g1=s1[1], delta_g1=s1[2], beta_g2=s2[0], delt
 keep = []
 crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(nv, l, A, B, C, keep), arrays, logm, keep))
 rs = bench.splitmix_fr(2, 9)
-for _ in range(4):
+for _ in range(14):
     t = time.perf_counter(); rc, proof = crs.prove(w, rs[0], rs[1]); print(rc, (time.perf_counter() - t) * 1e3, "ms", crs.stage_ms())

@@ -21,21 +21,26 @@
 //                      Buckets longer than heavy_t leave this kernel: they are cut into 512-entry parts
 //                      summed by one wavefront each (k_heavy_parts) and merged per bucket by an LDS tree
 //                      (k_heavy_merge), so no lane ever walks a long list alone
-//   7. k_bucket_reduce sum_b (b+1)*B_b per 2048-bucket chunk: per-lane running sums, then an LDS suffix
-//                      scan + tree reduction across the workgroup
+//   7. k_bucket_reduce sum_b (b+1)*B_b per 512-bucket chunk: per-lane running sums, then an LDS suffix
+//                      scan + tree reduction across the workgroup (a latency chain of ~20 additions)
 //   8. host            per-window chunk combine and the c-doublings Horner across windows
 // Zero scalars are dropped in step 1 and scalars equal to one simply land in bucket (window 0, digit 1),
 // a "heavy" bucket: the effect of libff's multi_exp_with_mixed_addition prefilter without a special case.
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 namespace zk {
 
 static constexpr int SCALAR_BITS = 255;      // r < 2^254; one extra bit absorbs the signed-digit carry
 static constexpr int RED_THREADS = 256;
-static constexpr int RED_L = 8;              // buckets per lane in the running-sum step
+static constexpr int RED_L_LOG = 2;          // 2 buckets per lane in the running-sum step: the kernel is a dependency chain of
+static constexpr int RED_L = 1 << RED_L_LOG; // 2(L-1) + 2 log2(256) + 2 additions, so a short L keeps its latency down
+static constexpr int RED_CHUNK_LOG = 8 + RED_L_LOG;
 static constexpr int RED_CHUNK = RED_THREADS * RED_L;
 static constexpr int MAX_C = 16;             // LDS histogram: 2^(c-1) u32 counters <= 128 KiB
 static constexpr uint32_t HEAVY_S = 512;     // entries per heavy part (one wavefront sums one part)
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *bu
     }
     if (t == 0) {
         XYZZ<F> E = sh[0];
-        for (int i = 0; i < 3; ++i) E = E.dbl();                    // * RED_L (= 8)
+        for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();            // * RED_L
         E.add(sh[RED_THREADS]);
         out[2 * (size_t)blockIdx.x] = P.normalized();
         out[2 * (size_t)blockIdx.x + 1] = E.normalized();
@@ -405,7 +410,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
-        if (!weighted.is_inf()) for (int i = 0; i < 11; ++i) weighted = weighted.dbl();   // * RED_CHUNK (2048)
+        if (!weighted.is_inf()) for (int i = 0; i < RED_CHUNK_LOG; ++i) weighted = weighted.dbl();   // * RED_CHUNK
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
     });
@@ -416,7 +421,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
     }
     return acc;
 }
-static_assert(RED_CHUNK == 2048 && RED_L == 8, "host combine assumes 2048-bucket chunks");
+static_assert(RED_THREADS == 256 && RED_CHUNK == (1 << RED_CHUNK_LOG), "chunk geometry");
 
 static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     const MsmGeom g = job->g; const size_t n = job->n;
@@ -468,10 +473,14 @@ void msm_job_destroy(MsmJob *j) {
 
 // enqueue: one digit sort of `d_scalars`, then one accumulate+reduce per base set (<= 2 G1 sets and <= 1 G2 set)
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont) {
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
     job->g = pick_geom(n); job->n = n;
     job->cpw = (job->g.B + RED_CHUNK - 1) / RED_CHUNK; job->nred = (size_t)job->g.W * job->cpw;
     if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
+    lap("sort enqueued");
     job->nslots = 0;
     for (int i = 0; i < n_g1; ++i) {
         MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = false;
@@ -481,6 +490,7 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
         MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = true;
         if (launch_accumulate<Fq2>(job, sl, d_g2_bases, n_g1 == 0)) return ZKG_ERROR;
     }
+    lap("accum enqueued");
     return ZKG_OK;
 }
 // wait for the job's stream and finish on the host; outputs in launch order (G1 sets, then the G2 set)

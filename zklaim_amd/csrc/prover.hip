@@ -295,6 +295,7 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
         (void)hipEventRecord(crs->ev[L.ev0], js);
         if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
         (void)hipEventRecord(crs->ev[L.ev0 + 1], js);
+        lap("  job enqueued");
     }
     lap("msm jobs enqueued");
     // host work that needs only the CRS and (r, s): overlaps the GPU
