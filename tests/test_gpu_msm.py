@@ -88,3 +88,33 @@ def test_msm_full_size_properties(zkg, oracle):
     lhs = zkg.msm_g1_dev(d_bases.data_ptr(), d_same.data_ptr(), k2)
     assert np.array_equal(lhs, oracle.g1_scalar_mul(psum[:8], s))
     assert total.any()
+
+
+def test_msm_adversarial_scalar_distributions(zkg, oracle):
+    """distributions that defeat a naive lane-per-bucket kernel: every scalar equal (one bucket per window holds everything),
+    only two distinct scalars, tiny scalars (high windows empty), scalars of the form 2^k (single non-zero digit), all r-1
+    (every signed digit negative or carrying)."""
+    n = 3000
+    _, bases, _ = dev_bases_g1(zkg, n, 4242)
+    rng = np.random.default_rng(11)
+    same = np.tile(random_fr_canonical(1, 5), (n, 1))
+    two = random_fr_canonical(2, 6)[rng.integers(0, 2, n)]
+    tiny = np.zeros((n, 4), np.uint64); tiny[:, 0] = rng.integers(0, 1000, n).astype(np.uint64)
+    pow2 = np.zeros((n, 4), np.uint64)
+    for i, k in enumerate(rng.integers(0, 253, n)):
+        pow2[i, k // 64] = np.uint64(1) << np.uint64(k % 64)
+    rm1 = np.tile(np.array(limbs(R - 1), np.uint64), (n, 1))
+    for name, sc in (("same", same), ("two", two), ("tiny", tiny), ("pow2", pow2), ("r-1", rm1)):
+        sc = np.ascontiguousarray(sc)
+        assert np.array_equal(zkg.msm_g1(bases, sc), oracle.msm_g1(bases, sc, oracle.MIXED)), name
+
+
+def test_msm_g2_larger_and_edges(zkg, oracle):
+    n = 3000
+    ks = random_fr_canonical(n, 199)
+    bases = oracle.g2_fixed_base(oracle.g2_generator(), ks)
+    sc = random_fr_canonical(n, 200)
+    sc[5] = limbs(R - 1); bases[7] = 0; bases[9] = bases[8]; sc[9] = sc[8]
+    assert np.array_equal(zkg.msm_g2(bases, sc), oracle.msm_g2(bases, sc))
+    assert np.array_equal(zkg.msm_g2(bases[:0], sc[:0]), g2_jac_expected(None))          # empty
+    assert np.array_equal(zkg.msm_g1(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)), g1_jac_expected(None))

@@ -17,7 +17,7 @@ def test_ntt_golden(zkg):
                 assert ints(out, R) == [h(x) for x in c[f"out_inv{inv}_coset{coset}"]], (c["logn"], inv, coset)
 
 
-@pytest.mark.parametrize("logn", [0, 1, 4, 9, 10, 11, 12, 13, 16, 17])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 4, 9, 10, 11, 12, 13, 15, 16, 17, 19, 21])
 def test_ntt_vs_oracle(zkg, oracle, logn):
     a = random_fr_canonical(1 << logn, 0x5A4B4C41494D0003 + logn)       # any 4-limb values < r are valid Montgomery residues
     for inv in (0, 1):

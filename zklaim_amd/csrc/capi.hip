@@ -35,13 +35,23 @@ int DevBuf::reserve(size_t bytes) {
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 KernelTimer g_dominant_timer;
+static std::mutex g_timer_mu;
+static constexpr size_t TIMER_MAX_PAIRS = 4096;              // a long-running host that never drains the timer stops recording here
 void KernelTimer::begin(hipStream_t s) {
-    if (!enabled) return;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    pending = false;
+    if (!enabled || used >= TIMER_MAX_PAIRS) return;
     if (used == pairs.size()) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; } pairs.push_back({a, b}); }
     (void)hipEventRecord(pairs[used].first, s);
+    pending = true;
 }
-void KernelTimer::end(hipStream_t s) { if (!enabled || used >= pairs.size()) return; (void)hipEventRecord(pairs[used].second, s); ++used; }
+void KernelTimer::end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (!pending) return;
+    (void)hipEventRecord(pairs[used].second, s); ++used; pending = false;
+}
 float KernelTimer::drain(int *launches) {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
     float total = 0; int n = 0;
     for (size_t i = 0; i < used; ++i) {
         float ms = 0;
@@ -50,7 +60,7 @@ float KernelTimer::drain(int *launches) {
     if (launches) *launches = n;
     return n ? total / n : 0.f;
 }
-void KernelTimer::reset() { used = 0; }
+void KernelTimer::reset() { std::lock_guard<std::mutex> lk(g_timer_mu); used = 0; pending = false; }
 
 // ---- host thread pool -------------------------------------------------------------------------------------
 namespace {

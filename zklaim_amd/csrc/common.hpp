@@ -27,7 +27,7 @@ struct DevBuf {
 
 // HIP-event timing of the dominant kernel (bench.py's roofline.achieved), on the launch stream
 struct KernelTimer {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs; size_t used = 0; bool enabled = true;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs; size_t used = 0; bool enabled = true, pending = false;
     void begin(hipStream_t s); void end(hipStream_t s);
     float drain(int *launches);       // average ms since last reset (synchronises the events)
     void reset();

@@ -471,6 +471,8 @@ void msm_job_destroy(MsmJob *j) {
     delete j;
 }
 
+static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex); only it feeds the kernel timer
+
 // enqueue: one digit sort of `d_scalars`, then one accumulate+reduce per base set (<= 2 G1 sets and <= 1 G2 set)
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont) {
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
@@ -484,11 +486,11 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     job->nslots = 0;
     for (int i = 0; i < n_g1; ++i) {
         MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = false;
-        if (launch_accumulate<Fq>(job, sl, d_g1_bases[i], true)) return ZKG_ERROR;
+        if (launch_accumulate<Fq>(job, sl, d_g1_bases[i], job == &g_default_job)) return ZKG_ERROR;
     }
     if (d_g2_bases) {
         MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = true;
-        if (launch_accumulate<Fq2>(job, sl, d_g2_bases, n_g1 == 0)) return ZKG_ERROR;
+        if (launch_accumulate<Fq2>(job, sl, d_g2_bases, n_g1 == 0 && job == &g_default_job)) return ZKG_ERROR;
     }
     lap("accum enqueued");
     return ZKG_OK;
@@ -504,7 +506,6 @@ int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
     return ZKG_OK;
 }
 
-static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex)
 
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s) {
