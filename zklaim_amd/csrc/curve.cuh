@@ -116,6 +116,45 @@ template <class F> struct XYZZ {
     }
 };
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// ---- quad-cooperative addition (device) ---------------------------------------------------------------------------
+// The tree / scan phases of the bucket reduction are dependency chains of additions with most lanes idle.  Here the four
+// lanes of a DPP quad hold IDENTICAL copies of both operands and share one addition: each lane multiplies a different pair
+// of operands (selected with v_cndmask, so the multiplication itself is one converged instruction stream) and the products
+// are broadcast back with v_mov_b32_dpp quad_perm.  14 dependent multiplications become 4 rounds.
+template <int S> ZK_D uint32_t quad_bcast_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S * 0x55, 0xf, 0xf, true); }
+template <int S> ZK_D Fq quad_bcast(const Fq &a) { Fq r; for (int i = 0; i < 8; ++i) r.v[i] = quad_bcast_u32<S>(a.v[i]); return r; }
+template <int S> ZK_D Fq2 quad_bcast(const Fq2 &a) { return {quad_bcast<S>(a.c0), quad_bcast<S>(a.c1)}; }
+ZK_D Fq quad_select(uint32_t q, const Fq &a0, const Fq &a1, const Fq &a2, const Fq &a3) {
+    Fq r;
+    for (int i = 0; i < 8; ++i) { uint32_t lo = q & 1 ? a1.v[i] : a0.v[i], hi = q & 1 ? a3.v[i] : a2.v[i]; r.v[i] = q & 2 ? hi : lo; }
+    return r;
+}
+ZK_D Fq2 quad_select(uint32_t q, const Fq2 &a0, const Fq2 &a1, const Fq2 &a2, const Fq2 &a3) {
+    return {quad_select(q, a0.c0, a1.c0, a2.c0, a3.c0), quad_select(q, a0.c1, a1.c1, a2.c1, a3.c1)};
+}
+// a += b; every lane of the quad passes the same a, b and receives the same sum.  q = lane & 3.
+template <class F> ZK_D void xyzz_add_quad(XYZZ<F> &a, const XYZZ<F> &b, uint32_t q) {
+    if (b.is_inf()) return;                                   // quad-uniform branches: all four lanes see the same data
+    if (a.is_inf()) { a = b; return; }
+    F m1 = quad_select(q, a.x, b.x, a.y, b.y) * quad_select(q, b.zz, a.zz, b.zzz, a.zzz);
+    F U1 = quad_bcast<0>(m1), U2 = quad_bcast<1>(m1), S1 = quad_bcast<2>(m1), S2 = quad_bcast<3>(m1);
+    F P = U2 - U1, R = S2 - S1;
+    if (__builtin_expect(P.is_zero(), 0)) {
+        if (R.is_zero()) { XYZZ<F> t = a.dbl(); a = t; } else a = XYZZ<F>::inf();
+        return;
+    }
+    F m2 = quad_select(q, P, R, a.zz, a.zzz) * quad_select(q, P, R, b.zz, b.zzz);
+    F PP = quad_bcast<0>(m2), RR = quad_bcast<1>(m2), ZZ12 = quad_bcast<2>(m2), ZZZ12 = quad_bcast<3>(m2);
+    F m3 = quad_select(q, P, U1, ZZ12, ZZ12) * PP;           // lane 3 repeats lane 2's product
+    F PPP = quad_bcast<0>(m3), Q = quad_bcast<1>(m3), ZZ3 = quad_bcast<2>(m3);
+    F X3 = RR - PPP - Q.dbl();
+    F m4 = quad_select(q, R, S1, ZZZ12, ZZZ12) * quad_select(q, Q - X3, PPP, PPP, PPP);
+    F Y3 = quad_bcast<0>(m4) - quad_bcast<1>(m4);
+    a.x = X3; a.y = Y3; a.zz = ZZ3; a.zzz = quad_bcast<2>(m4);
+}
+#endif
+
 typedef Affine<Fq> G1Affine;  typedef XYZZ<Fq> G1;
 typedef Affine<Fq2> G2Affine; typedef XYZZ<Fq2> G2;
 

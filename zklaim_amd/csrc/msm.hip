@@ -21,8 +21,8 @@
 //                      Buckets longer than heavy_t leave this kernel: they are cut into 512-entry parts
 //                      summed by one wavefront each (k_heavy_parts) and merged per bucket by an LDS tree
 //                      (k_heavy_merge), so no lane ever walks a long list alone
-//   7. k_bucket_reduce sum_b (b+1)*B_b per 512-bucket chunk: per-lane running sums, then an LDS suffix
-//                      scan + tree reduction across the workgroup (a latency chain of ~20 additions)
+//   7. k_bucket_reduce sum_b (b+1)*B_b per chunk of 512 or 2048 buckets: per-lane running sums, then an LDS suffix
+//                      scan + tree reduction across the workgroup; every addition is shared by a DPP quad
 //   8. host            per-window chunk combine and the c-doublings Horner across windows
 // Zero scalars are dropped in step 1 and scalars equal to one simply land in bucket (window 0, digit 1),
 // a "heavy" bucket: the effect of libff's multi_exp_with_mixed_addition prefilter without a special case.
@@ -37,11 +37,13 @@
 namespace zk {
 
 static constexpr int SCALAR_BITS = 255;      // r < 2^254; one extra bit absorbs the signed-digit carry
-static constexpr int RED_THREADS = 256;
-static constexpr int RED_L_LOG = 2;          // 2 buckets per lane in the running-sum step: the kernel is a dependency chain of
-static constexpr int RED_L = 1 << RED_L_LOG; // 2(L-1) + 2 log2(256) + 2 additions, so a short L keeps its latency down
-static constexpr int RED_CHUNK_LOG = 8 + RED_L_LOG;
-static constexpr int RED_CHUNK = RED_THREADS * RED_L;
+static constexpr int RED_LANES = 128;         // logical lanes per reduce workgroup, four physical lanes (one DPP quad) each
+static constexpr int RED_THREADS = 4 * RED_LANES;
+// buckets per logical lane in the running-sum step, 2^L_LOG: the kernel is a dependency chain of 2(L-1) + 2 log2(128) + 2
+// additions but does (2(L-1) + 14)/L additions per bucket, so small bucket sets (latency-bound: the prover's witness MSMs)
+// take L = 4 and large ones (work-bound: 2^19 buckets at N = 2^20) take L = 16.
+static constexpr int RED_L_LOG_SMALL = 2, RED_L_LOG_LARGE = 4;
+static constexpr size_t RED_LARGE_BUCKETS = (size_t)1 << 18;
 static constexpr int MAX_C = 16;             // LDS histogram: 2^(c-1) u32 counters <= 128 KiB
 static constexpr uint32_t HEAVY_S = 512;     // entries per heavy part (one wavefront sums one part)
 static constexpr uint32_t HEAVY_T_MAX = 1024;
@@ -296,48 +298,51 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
     }
 }
 
-// ---- 7. bucket reduction: per chunk of RED_CHUNK buckets emit P = sum X_i and U = sum i*X_i (i 0-based in chunk)
-template <class F>
+// ---- 7. bucket reduction: per chunk of RED_CHUNK buckets emit P = sum X_i and U = sum i*X_i (i 0-based in chunk).
+//      RED_LANES logical lanes per workgroup, each played by the four lanes of a DPP quad (xyzz_add_quad): the kernel is a
+//      dependency chain of 2(L-1) + 2 log2(RED_LANES) + 2 additions, and the quad turns each addition's 14 dependent
+//      multiplications into 4 rounds.
+template <class F, int RED_L_LOG>
 __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out) {
+    constexpr int RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);              // 2 * RED_THREADS points
-    const uint32_t t = threadIdx.x, w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);              // 2 * RED_LANES points
+    const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;          // logical lane, position in its quad
+    const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
     const XYZZ<F> *X = buckets + (size_t)w * B;
     const uint32_t base = ch * RED_CHUNK + t * RED_L;
     // lane-local running sums: S = sum_j X_j, T0 = sum_j j*X_j
     XYZZ<F> run = XYZZ<F>::inf(), T0 = XYZZ<F>::inf();
     for (int j = RED_L - 1; j >= 1; --j) {
-        if (base + j < B) run.add(X[base + j]);
-        T0.add(run);
+        if (base + j < B) xyzz_add_quad(run, X[base + j], q);
+        xyzz_add_quad(T0, run, q);
     }
-    if (base < B) run.add(X[base]);
-    // inclusive suffix scan of S over lanes (Hillis-Steele through LDS): Q_t = sum_{u>=t} S_u
+    if (base < B) xyzz_add_quad(run, X[base], q);
+    // inclusive suffix scan of S over logical lanes (Hillis-Steele through LDS): Q_t = sum_{u>=t} S_u
     XYZZ<F> Q = run;
-    for (uint32_t d = 1; d < RED_THREADS; d <<= 1) {
-        sh[t] = Q;
+    for (uint32_t d = 1; d < RED_LANES; d <<= 1) {
+        if (q == 0) sh[t] = Q;
         __syncthreads();
-        if (t + d < RED_THREADS) Q.add(sh[t + d]);
+        if (t + d < RED_LANES) xyzz_add_quad(Q, sh[t + d], q);
         __syncthreads();
     }
-    // sum_t t*S_t = sum_{t>=1} Q_t ; tree-reduce Q (t>=1) in sh[0..), T0 in sh[RED_THREADS..)
-    XYZZ<F> P = Q;                                                  // lane 0: total of the chunk
-    sh[t] = (t >= 1) ? Q : XYZZ<F>::inf();
-    sh[RED_THREADS + t] = T0;
+    // sum_t t*S_t = sum_{t>=1} Q_t ; tree-reduce Q (t>=1) in sh[0..), T0 in sh[RED_LANES..)
+    XYZZ<F> P = Q;                                                  // logical lane 0: total of the chunk
+    if (q == 0) { sh[t] = (t >= 1) ? Q : XYZZ<F>::inf(); sh[RED_LANES + t] = T0; }
     __syncthreads();
-    for (uint32_t d = RED_THREADS / 2; d >= 1; d >>= 1) {
-        if (t < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
-        else if (t >= RED_THREADS / 2 && t < RED_THREADS / 2 + d) {
-            uint32_t u = RED_THREADS + (t - RED_THREADS / 2);
-            XYZZ<F> a = sh[u]; a.add(sh[u + d]); sh[u] = a;
+    for (uint32_t d = RED_LANES / 2; d >= 1; d >>= 1) {
+        if (t < d) { XYZZ<F> a = sh[t]; xyzz_add_quad(a, sh[t + d], q); if (q == 0) sh[t] = a; }
+        else if (t >= RED_LANES / 2 && t < RED_LANES / 2 + d) {
+            uint32_t u = RED_LANES + (t - RED_LANES / 2);
+            XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + d], q); if (q == 0) sh[u] = a;
         }
         __syncthreads();
     }
     if (t == 0) {
         XYZZ<F> E = sh[0];
         for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();            // * RED_L
-        E.add(sh[RED_THREADS]);
-        out[2 * (size_t)blockIdx.x] = P.normalized();
-        out[2 * (size_t)blockIdx.x + 1] = E.normalized();
+        xyzz_add_quad(E, sh[RED_LANES], q);
+        if (q == 0) { out[2 * (size_t)blockIdx.x] = P.normalized(); out[2 * (size_t)blockIdx.x + 1] = E.normalized(); }
     }
 }
 
@@ -363,7 +368,7 @@ struct MsmJob {
     hipStream_t stream = nullptr; bool own_stream = false;
     DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted;
     MsmSlot slot[3]; int nslots = 0;
-    MsmGeom g{}; size_t n = 0; uint32_t cpw = 0; size_t nred = 0;
+    MsmGeom g{}; size_t n = 0; uint32_t cpw = 0; size_t nred = 0; int red_l_log = RED_L_LOG_SMALL;
     std::mutex mu;
 };
 
@@ -388,8 +393,12 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
                        d_bases, job->sorted.as<uint32_t>(), sl.heavy_items.as<HeavyItem>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>());
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
                        sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>(), buckets);
-    hipLaunchKernelGGL(k_bucket_reduce<F>, dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_THREADS * sizeof(XYZZ<F>), s,
-                       buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
+    if (job->red_l_log == RED_L_LOG_LARGE)
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_LANES * sizeof(XYZZ<F>), s,
+                           buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
+    else
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_LANES * sizeof(XYZZ<F>), s,
+                           buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
     ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, job->nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
     return ZKG_OK;
@@ -410,7 +419,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
-        if (!weighted.is_inf()) for (int i = 0; i < RED_CHUNK_LOG; ++i) weighted = weighted.dbl();   // * RED_CHUNK
+        if (!weighted.is_inf()) for (int i = 0; i < 7 + job->red_l_log; ++i) weighted = weighted.dbl();   // * chunk size (128 * L)
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
     });
@@ -421,7 +430,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
     }
     return acc;
 }
-static_assert(RED_THREADS == 256 && RED_CHUNK == (1 << RED_CHUNK_LOG), "chunk geometry");
+static_assert(RED_LANES == 128, "chunk geometry: 128 logical lanes");
 
 static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     const MsmGeom g = job->g; const size_t n = job->n;
@@ -480,7 +489,9 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
     job->g = pick_geom(n); job->n = n;
-    job->cpw = (job->g.B + RED_CHUNK - 1) / RED_CHUNK; job->nred = (size_t)job->g.W * job->cpw;
+    job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
+    { uint32_t chunk = RED_LANES << job->red_l_log; job->cpw = (job->g.B + chunk - 1) / chunk; }
+    job->nred = (size_t)job->g.W * job->cpw;
     if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
     lap("sort enqueued");
     job->nslots = 0;
@@ -554,8 +565,8 @@ int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1A
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s) { return fixed_base<Fq2>(base, d_scalars, n, d_out, s); }
 
 int msm_configure() {
-    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_THREADS * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_THREADS * (int)sizeof(G1)) == hipSuccess;
+    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_LANES * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
