@@ -247,6 +247,20 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, co
     buckets[gb] = acc.normalized();
 }
 
+// LDS tree reduction of seg[0..n) into seg[0] by `nthreads` threads (tid = 0..nthreads-1, n a power of two <= nthreads;
+// every thread of the group must call it; barrier() synchronises the group).  Levels with at most nthreads/4 pairs share
+// each addition across a DPP quad (nthreads is a multiple of 64, so quads never straddle groups).
+template <class F, class Barrier>
+ZK_D void lds_tree_reduce(XYZZ<F> *seg, uint32_t n, uint32_t tid, uint32_t nthreads, Barrier barrier) {
+    for (uint32_t d = n / 2; d >= 1; d >>= 1) {
+        if (4 * d <= nthreads) {
+            uint32_t t = tid >> 2, q = tid & 3;
+            if (t < d) { XYZZ<F> a = seg[t]; xyzz_add_quad(a, seg[t + d], q); if (q == 0) seg[t] = a; }
+        } else if (tid < d) { XYZZ<F> a = seg[tid]; a.add(seg[tid + d]); seg[tid] = a; }
+        barrier();
+    }
+}
+
 // one wavefront per heavy part: 64 lanes stride over <= HEAVY_S entries, then a 6-level LDS tree
 template <class F>
 __global__ __launch_bounds__(256) void k_heavy_parts(const Affine<F> *bases, const uint32_t *sorted, const HeavyItem *items,
@@ -268,10 +282,7 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const Affine<F> *bases, con
         }
         sh[t] = acc;
         __syncthreads();
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            if (lane < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
-            __syncthreads();
-        }
+        lds_tree_reduce<F>(sh + wv * 64, 64, lane, 64, [] { __syncthreads(); });      // the four wavefronts run their trees in step
         if (lane == 0 && it < n_items) partials[it] = sh[t].normalized();
         __syncthreads();
     }
@@ -289,10 +300,7 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
         for (uint32_t p = t; p < h.nparts; p += 256) acc.add(partials[h.first_item + p]);
         sh[t] = acc;
         __syncthreads();
-        for (uint32_t d = 128; d >= 1; d >>= 1) {
-            if (t < d) { XYZZ<F> a = sh[t]; a.add(sh[t + d]); sh[t] = a; }
-            __syncthreads();
-        }
+        lds_tree_reduce<F>(sh, 256, t, 256, [] { __syncthreads(); });
         if (t == 0) buckets[h.gb] = sh[0].normalized();
         __syncthreads();
     }
