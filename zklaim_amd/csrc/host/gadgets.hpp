@@ -23,10 +23,10 @@ struct Bit {
     bool is_const() const { return konst >= 0; }
     Bit operator!() const { Bit b = *this; if (is_const()) b.konst = 1 - konst; else b.neg = !neg; return b; }
     LC lc() const { if (is_const()) return LC::constant((uint64_t)konst); return neg ? LC::constant(1) - LC(v) : LC(v); }
-    bool value(const Builder &pb) const { if (is_const()) return konst != 0; bool x = !pb.val[v].is_zero(); return neg ? !x : x; }
+    bool value(const Builder &pb) const { if (is_const()) return konst != 0; bool x = pb.nz[v] != 0; return neg ? !x : x; }
 };
 
-inline Bit new_bit(Builder &pb, bool value) { Var v = pb.alloc(); pb.val[v] = value ? Fr::one() : Fr::zero(); return Bit::var(v); }
+inline Bit new_bit(Builder &pb, bool value) { Var v = pb.alloc(); pb.set_bit(v, value); return Bit::var(v); }
 
 inline Bit bit_xor(Builder &pb, Bit a, Bit b) {
     if (a.is_const()) return a.konst ? !b : b;
@@ -144,8 +144,8 @@ inline void enforce_packing(Builder &pb, const std::vector<Var> &bits, size_t lo
 }
 inline void assign_packing(Builder &pb, const std::vector<Var> &bits, size_t lo, size_t hi, Var packed) {
     Fr s = Fr::zero(), w = Fr::one();
-    for (size_t i = lo; i < hi; ++i) { if (!pb.val[bits[i]].is_zero()) s += w; w = w.dbl(); }
-    pb.val[packed] = s;
+    for (size_t i = lo; i < hi; ++i) { if (pb.nz[bits[i]]) s += w; w = w.dbl(); }
+    pb.set(packed, s);
 }
 
 // comparison of two n-bit values (libsnark comparison_gadget semantics): less = [A < B], less_or_eq = [A <= B].
@@ -170,15 +170,15 @@ inline void comparison_witness(Builder &pb, const Comparison &c, size_t n, uint6
     // n == 64: alpha = 2^64 + b - a as a 65-bit integer
     unsigned __int128 alpha = ((unsigned __int128)1 << n) + b - a;
     uint64_t cnt = 0;
-    for (size_t i = 0; i <= n; ++i) { bool bit = (alpha >> i) & 1; pb.val[c.alpha[i]] = bit ? Fr::one() : Fr::zero(); if (i < n && bit) ++cnt; }
+    for (size_t i = 0; i <= n; ++i) { bool bit = (alpha >> i) & 1; pb.set_bit(c.alpha[i], bit); if (i < n && bit) ++cnt; }
     Fr packed = Fr::from_u64((uint64_t)alpha);
     if ((alpha >> 64) & 1) { Fr t = Fr::one(); for (int i = 0; i < 64; ++i) t = t.dbl(); packed += t; }
-    pb.val[c.alpha_packed] = packed;
-    pb.val[c.not_all_zeros] = cnt ? Fr::one() : Fr::zero();
-    pb.val[c.inv] = cnt ? Fr::from_u64(cnt).inverse() : Fr::zero();
+    pb.set(c.alpha_packed, packed);
+    pb.set_bit(c.not_all_zeros, cnt != 0);
+    pb.set(c.inv, cnt ? Fr::from_u64(cnt).inverse() : Fr::zero());
     bool leq = (alpha >> n) & 1;
-    pb.val[less_or_eq] = leq ? Fr::one() : Fr::zero();
-    pb.val[less] = (leq && cnt) ? Fr::one() : Fr::zero();
+    pb.set_bit(less_or_eq, leq);
+    pb.set_bit(less, leq && cnt);
 }
 
 }}  // namespace zk::circuit

@@ -31,11 +31,15 @@ struct Constraint { LC a, b, c; };
 
 struct Builder {
     std::vector<Fr> val;                 // val[0] == 1
+    std::vector<uint8_t> nz;             // nz[v] = (val[v] != 0): what the boolean gadgets read on the witness path
     std::vector<Constraint> cons;
     uint32_t num_inputs = 0;
     bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
-    Builder() { val.push_back(Fr::one()); }
-    Var alloc() { val.push_back(Fr::zero()); return (Var)(val.size() - 1); }
+    Builder() { val.push_back(Fr::one()); nz.push_back(1); }
+    void reserve(size_t nvars) { val.reserve(nvars + 1); nz.reserve(nvars + 1); }
+    Var alloc() { val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1); }
+    void set(Var v, const Fr &x) { val[v] = x; nz[v] = !x.is_zero(); }
+    void set_bit(Var v, bool b) { val[v] = b ? Fr::one() : Fr::zero(); nz[v] = b; }
     std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
     void set_input_sizes(uint32_t n) { num_inputs = n; }
     uint32_t num_variables() const { return (uint32_t)val.size() - 1; }

@@ -78,7 +78,12 @@ inline void get_fq12(const uint8_t *p, pairing::Fq12 &g) {
 
 struct Writer {
     std::vector<uint8_t> buf;
-    void dec(size_t v) { char t[32]; int n = snprintf(t, sizeof t, "%zu\n", v); buf.insert(buf.end(), t, t + n); }
+    void dec(size_t v) {                                     // ASCII decimal + '\n' (millions of these in a pk: no snprintf)
+        char t[24]; int n = 0;
+        do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) buf.push_back((uint8_t)t[--n]);
+        buf.push_back('\n');
+    }
     void raw(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; buf.insert(buf.end(), b, b + n); }
     void g1(const G1Affine &a) { uint8_t t[34]; put_g1(t, a); raw(t, 34); }
     void g2(const G2Affine &a) { uint8_t t[66]; put_g2(t, a); raw(t, 66); }

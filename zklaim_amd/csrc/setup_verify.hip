@@ -170,6 +170,7 @@ int zkg_keypair_swapped(const zkg_keypair *kp) { return kp && kp->swapped ? 1 : 
 size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
     if (!kp) return 0;
     ser::Writer w;
+    w.buf.reserve((kp->A_query.size() + kp->H_query.size() + kp->L_query.size()) * 34 + kp->B_g2.size() * 108 + (kp->col[0].size() + kp->col[1].size() + kp->col[2].size()) * 40 + (size_t)kp->C * 8 + 4096);
     w.g1(kp->alpha_g1); w.g1(kp->beta_g1); w.g2(kp->beta_g2); w.g1(kp->delta_g1); w.g2(kp->delta_g2);
     w.dec(kp->A_query.size()); for (auto &p : kp->A_query) w.g1(p);
     std::vector<size_t> idx;

@@ -61,6 +61,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
     zkg_circuit *ck = new zkg_circuit();
     Builder &pb = ck->pb;
     pb.recording = !witness_only;                           // proving: the resident key already holds the constraint system
+    pb.reserve(28000 * (ctx->num_of_payloads + 1));
     const size_t k = ctx->num_of_payloads;
     const bool bind_packings = getenv("ZKG_BIND_PACKINGS") != nullptr;
     std::vector<const zklaim_payload *> pls;
@@ -91,12 +92,12 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
     // ---- witness values that do not depend on gadget internals (zklaim_gadget.cpp:705-783)
     std::vector<std::array<uint64_t, 5>> attr(k), refv(k);
     if (with_witness) {
-        pb.val[zero] = Fr::zero();
+        pb.set_bit(zero, false);
         for (size_t i = 0; i < k; ++i) {
             const zklaim_payload &pl = *pls[i];
             unsigned char refs[64], ops[64];
             payload_public_bytes(pl, refs, ops);
-            auto set_bits = [&](const std::vector<Var> &vars, const std::vector<bool> &bv) { for (size_t b = 0; b < vars.size(); ++b) pb.val[vars[b]] = bv[b] ? Fr::one() : Fr::zero(); };
+            auto set_bits = [&](const std::vector<Var> &vars, const std::vector<bool> &bv) { for (size_t b = 0; b < vars.size(); ++b) pb.set_bit(vars[b], bv[b]); };
             set_bits(r_bits[i], memtobv(pl.pre, 384));
             set_bits(h_bits[i], memtobv(pl.hash, 256));
             set_bits(ref_bits[i], memtobv(refs, 512));
@@ -104,7 +105,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
             for (int j = 0; j < 5; ++j) {
                 memcpy(&attr[i][j], pl.pre + 8 * j, 8);                        // extractFromBV: little-endian u64 of the slot
                 refv[i][j] = pl.data_ref[j];
-                pb.val[data[i][j]] = Fr::from_u64(attr[i][j]);
+                pb.set(data[i][j], Fr::from_u64(attr[i][j]));
             }
         }
         for (size_t c = 0; c < n_inputs; ++c) assign_packing(pb, input_as_bits, c * FR_CAPACITY, std::min(input_bits, (c + 1) * FR_CAPACITY), input_fe[c]);
