@@ -6,6 +6,7 @@ unless stated, G1 affine 8 limbs, G2 affine 16 limbs, normalised "jac" outputs 1
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +49,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             raise ZkgError(f"{_SO} is missing: build it with `python -m zklaim_amd.build` (hipcc, gfx950)")
+        # One ROCm stack per process: PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If libzkg.so pulled in the
+        # system copies first and torch loaded afterwards, two HSA runtimes would coexist and device discovery fails.  When torch
+        # is installed, let it load its runtime first; libzkg.so's libamdhip64.so.7 dependency then resolves to the same objects.
+        if "torch" not in sys.modules and not os.environ.get("ZKG_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(_SO)
         _lib.zkg_last_error.restype = C.c_char_p
         _lib.zkg_timing_dominant_ms.restype = C.c_float
