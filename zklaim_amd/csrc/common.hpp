@@ -55,7 +55,8 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s);     // cached per size
 // mode: inverse / coset as in zkg_ntt.  extra_post (device, N Fr, optional) replaces the default
 // post table: the prover fuses iFFT's 1/N with the following cosetFFT's g^i through it.
 int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s);
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr);
+// batch > 1: `batch` vectors of N elements back to back in d_a (and in `scratch`, which must then be given), one launch per pass
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr, unsigned batch = 1);
 int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s);   // out[i] = scale * base^i
 void ntt_release_all();
 int ntt_configure();

@@ -497,6 +497,7 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
     job->g = pick_geom(n); job->n = n;
+    if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
     job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
     { uint32_t chunk = RED_LANES << job->red_l_log; job->cpw = (job->g.B + chunk - 1) / chunk; }
     job->nred = (size_t)job->g.W * job->cpw;

@@ -28,6 +28,7 @@ struct NttPassArgs {
     const Fr *src; Fr *dst; const Fr *tw; const Fr *pre; const Fr *post;
     Fr post_scalar;
     uint32_t n_log, s0, R, cw_log, first, has_post_scalar;
+    size_t src_batch_stride, dst_batch_stride;      // elements between the vectors of a batch (blockIdx.y)
 };
 
 ZK_D uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     extern __shared__ U4 smem[];
     const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = 2 * CW + 1;   // +1 x 16 B pad per row
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    A.src += (size_t)blockIdx.y * A.src_batch_stride; A.dst += (size_t)blockIdx.y * A.dst_batch_stride;
     const uint32_t s1 = A.s0 + A.R;
     const uint32_t lo_mask = (1u << A.s0) - 1;
     auto lds_ld = [&](uint32_t row, uint32_t c) { Fr r; const U4 *p = &smem[row * stride + 2 * c]; *reinterpret_cast<U4 *>(&r.v[0]) = p[0]; *reinterpret_cast<U4 *>(&r.v[4]) = p[1]; return r; };
@@ -156,7 +158,7 @@ void ntt_release_all() {
     g_domains.clear();
 }
 
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch) {
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch, unsigned batch) {
     const unsigned n = d->logn;
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
     const size_t N = (size_t)1 << n;
@@ -178,13 +180,14 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
         A.has_post_scalar = (p == npass - 1 && post_scalar && !post) ? 1 : 0;
         A.post_scalar = A.has_post_scalar ? *post_scalar : Fr::zero();
         A.n_log = n; A.s0 = s0; A.R = R;
+        A.src_batch_stride = N; A.dst_batch_stride = N;     // batched vectors (and their scratch) are laid out back to back
         unsigned cols_log = n - R;                                   // columns in total
         A.cw_log = cols_log < (unsigned)(NTT_TILE_LOG - R) ? cols_log : (unsigned)(NTT_TILE_LOG - R);
         if (npass == 1) A.cw_log = 0;
         size_t tiles = (N >> R) >> A.cw_log;
         size_t rows = (size_t)1 << R, CW = (size_t)1 << A.cw_log;
         size_t lds = rows * (2 * CW + 1) * 16;
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, s, A);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, batch), dim3(NTT_THREADS), lds, s, A);
         if (hipGetLastError() != hipSuccess) { set_error("ntt pass launch failed"); return ZKG_ERROR; }
         s0 += R;
     }

@@ -32,12 +32,11 @@ struct zkg_crs {
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
     zk::NttDomain *dom = nullptr;
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
-    zk::DevBuf z, aA, aB, aC, flag;             // [1 | w] and the three evaluation vectors
+    zk::DevBuf z, aABC, flag;                   // [1 | w] and the three evaluation vectors aA | aB | aC back to back (batched NTTs)
     zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
-    zk::DevBuf ntt_scratch[3];                  // this CRS's own inter-pass vectors (one per concurrent transform chain)
+    zk::DevBuf ntt_scratch;                     // this CRS's own inter-pass scratch, 3 m elements (the batched transforms)
     hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
-    hipStream_t side[2] = {nullptr, nullptr};   // the B and C transform chains run beside the A chain
     zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;   // concurrent MSMs, one stream + workspace each
     float stage_ms[8] = {0};
     hipEvent_t ev[20]; bool ev_ok = false;
@@ -140,7 +139,7 @@ static size_t ser_g2(uint8_t *out, const G2 &p) {
 
 static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint32_t *flag_out, hipStream_t s) {
     const size_t m = crs->m;
-    Fr *z = crs->z.as<Fr>(), *aA = crs->aA.as<Fr>(), *aB = crs->aB.as<Fr>(), *aC = crs->aC.as<Fr>();
+    Fr *z = crs->z.as<Fr>(), *aA = crs->aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
     if (crs->n) ZK_HIP(hipMemcpyAsync(z + 1, witness, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
     ZK_HIP(hipMemsetAsync(crs->flag.p, 0, 4, s));
@@ -160,19 +159,13 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
         ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
     }
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
-    // iFFT then cosetFFT for each of aA, aB, aC — three independent chains, run concurrently (a 2^18 transform fills half the
-    // chip): inverse transform with the fused post table g^i/m, then a plain forward transform
+    // iFFT then cosetFFT of aA, aB, aC as ONE batch of three (a single 2^18 transform fills half the chip; three fill it):
+    // inverse transform with the fused post table g^i/m, then a plain forward transform
     const Fr *fused = crs->coset_over_m.as<Fr>();
-    Fr *vecs[3] = {aA, aB, aC};
-    hipStream_t chain[3] = {s, crs->side[0], crs->side[1]};
-    for (int k = 0; k < 3; ++k) {
-        if (k) ZK_HIP(hipStreamWaitEvent(chain[k], crs->ev[1], 0));
-        if (ntt_run_ex(crs->dom, vecs[k], true, nullptr, fused, nullptr, chain[k], crs->ntt_scratch[k].as<Fr>())) return ZKG_ERROR;
-        if (ntt_run_ex(crs->dom, vecs[k], false, nullptr, nullptr, nullptr, chain[k], crs->ntt_scratch[k].as<Fr>())) return ZKG_ERROR;
-        if (k) { (void)hipEventRecord(crs->ev[16 + k], chain[k]); ZK_HIP(hipStreamWaitEvent(s, crs->ev[16 + k], 0)); }
-    }
+    if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, crs->ntt_scratch.as<Fr>(), 3)) return ZKG_ERROR;
+    if (ntt_run_ex(crs->dom, aA, false, nullptr, nullptr, nullptr, s, crs->ntt_scratch.as<Fr>(), 3)) return ZKG_ERROR;
     hipLaunchKernelGGL(k_pointwise_h, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
-    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch[0].as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
+    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
     if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
@@ -218,15 +211,13 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         Fr g = Fr::from_u64(5);
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
         ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
-             crs->z.reserve((n + 1) * 32) == 0 && crs->aA.reserve(m * 32) == 0 && crs->aB.reserve(m * 32) == 0 && crs->aC.reserve(m * 32) == 0 &&
-             crs->flag.reserve(4) == 0 && crs->ntt_scratch[0].reserve(m * 32) == 0 && crs->ntt_scratch[1].reserve(m * 32) == 0 && crs->ntt_scratch[2].reserve(m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+             crs->z.reserve((n + 1) * 32) == 0 && crs->aABC.reserve(3 * m * 32) == 0 &&
+             crs->flag.reserve(4) == 0 && crs->ntt_scratch.reserve(3 * m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
     }
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
-        ok = hip_ok(hipStreamCreateWithPriority(&crs->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__) &&
-             hip_ok(hipStreamCreateWithPriority(&crs->side[0], hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__) &&
-             hip_ok(hipStreamCreateWithPriority(&crs->side[1], hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
+        ok = hip_ok(hipStreamCreateWithPriority(&crs->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
         crs->job_a = msm_job_create(nullptr, true); crs->job_b1 = msm_job_create(nullptr, true); crs->job_b2 = msm_job_create(nullptr, true);
         crs->job_h = msm_job_create(nullptr, true, true); crs->job_l = msm_job_create(nullptr, true);
         ok = ok && crs->job_a && crs->job_b1 && crs->job_b2 && crs->job_h && crs->job_l;
@@ -243,12 +234,11 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
-                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aA, &crs->aB, &crs->aC, &crs->flag,
-                      &crs->ntt_scratch[0], &crs->ntt_scratch[1], &crs->ntt_scratch[2], &crs->long_rows})
+                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aABC, &crs->flag,
+                      &crs->ntt_scratch, &crs->long_rows})
         b->release();
     msm_job_destroy(crs->job_a); msm_job_destroy(crs->job_b1); msm_job_destroy(crs->job_b2); msm_job_destroy(crs->job_h); msm_job_destroy(crs->job_l);
     if (crs->stream) (void)hipStreamDestroy(crs->stream);
-    for (auto &st : crs->side) if (st) (void)hipStreamDestroy(st);
     if (crs->ev_ok) for (auto &e : crs->ev) (void)hipEventDestroy(e);
     delete crs;
 }
@@ -260,7 +250,7 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
     uint32_t flag = 0;
     if (compute_h(crs, witness, false, &flag, crs->stream)) return ZKG_ERROR;
     ZK_HIP(hipStreamSynchronize(crs->stream));
-    ZK_HIP(hipMemcpy(h_out, crs->aA.p, crs->m * 32, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(h_out, crs->aABC.p, crs->m * 32, hipMemcpyDeviceToHost));
     memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
     return ZKG_OK;
 }
@@ -288,7 +278,7 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
         {crs->job_a, crs->A_query.as<G1Affine>(), nullptr, z, n + 1, 0, 5},
         {crs->job_b1, crs->B_g1.as<G1Affine>(), nullptr, z, n + 1, 0, 7},
         {crs->job_l, crs->L_query.as<G1Affine>(), nullptr, z + 8 * (l + 1), n - l, 0, 9},
-        {crs->job_h, crs->H_query.as<G1Affine>(), nullptr, crs->aA.as<uint32_t>(), m - 1, 2, 11}};
+        {crs->job_h, crs->H_query.as<G1Affine>(), nullptr, crs->aABC.as<uint32_t>(), m - 1, 2, 11}};
     for (const Launch &L : launches) {
         hipStream_t js = msm_job_stream(L.job);
         ZK_HIP(hipStreamWaitEvent(js, crs->ev[L.wait_ev], 0));
