@@ -91,7 +91,7 @@ def extras(zkg, torch, args, with_cpu):
     nv, l, ncons = ck.r1cs.num_variables, ck.r1cs.num_inputs, ck.r1cs.num_constraints
     w = ck.witness()
     kp = zkg.Keypair(ck.r1cs, splitmix_fr(5, SEED + 4))
-    m = 1 << kp.pk.log_m
+    m = kp.pk.domain_size or (1 << kp.pk.log_m)
     logm = kp.pk.log_m
     t_setup = time.perf_counter() - t_syn
     crs = zkg.Crs(kp.pk)

@@ -62,8 +62,10 @@ typedef struct zkg_r1cs {
  *      absent entries are infinity.                                                   */
 typedef struct zkg_pk {
     zkg_r1cs cs;               /* the (possibly A/B-swapped) system stored in the pk   */
-    uint32_t log_m;            /* evaluation domain size m = 2^log_m                   */
-    uint32_t reserved;
+    uint32_t log_m;            /* ceil(log2 m) of the evaluation domain size m         */
+    uint32_t domain_size;      /* m as libfqfft's get_evaluation_domain(C+l+1) picks it:
+                                  2^log_m (basic_radix2_domain; 0 means the same) or
+                                  2^(log_m-1) + 2^b, b < log_m-1 (step_radix2_domain)   */
     const uint64_t *alpha_g1, *beta_g1, *delta_g1;   /* 8 limbs each                   */
     const uint64_t *beta_g2, *delta_g2;              /* 16 limbs each                  */
     const uint64_t *A_query;   /* (n+1) x 8                                            */
@@ -93,6 +95,20 @@ int  zkg_device_info(char *name, size_t name_len, int *compute_units);
  *      coset:   0 plain, 1 coset with g = Fr::multiplicative_generator (= 5).         */
 int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset);
 int zkg_ntt_dev(void *d_a, unsigned logN, int inverse, int coset, void *stream);
+
+/* ---- Domain choice and the non-power-of-two case.
+ *      zkg_evaluation_domain_size: libfqfft::get_evaluation_domain(min_size) as
+ *      r1cs_to_qap_instance_map / _witness_map call it with min_size = C + l + 1
+ *      (inside snark.cpp:91 and :126): *m = the domain size, *is_step = 1 when it is a
+ *      step_radix2_domain (m = 2^a + 2^b, b < a) instead of a basic_radix2_domain.
+ *      zklaim's circuit lands on a step domain for 10 of its 20 payload counts
+ *      (e.g. 3 payloads: m = 2^16 + 2^15).
+ *      zkg_ntt_domain: the same four transforms as zkg_ntt on the domain of size m,
+ *      m = 2^k or 2^a + 2^b: libfqfft step_radix2_domain<Fr>::FFT / iFFT / cosetFFT /
+ *      icosetFFT for the latter.  a: m Fr elements, Montgomery, in place.             */
+int zkg_evaluation_domain_size(size_t min_size, size_t *m, int *is_step);
+int zkg_ntt_domain(uint64_t *a, size_t m, int inverse, int coset);
+int zkg_ntt_domain_dev(void *d_a, size_t m, int inverse, int coset, void *stream);
 
 /* ---- MSM: libff::multi_exp<G1,Fr,multi_exp_method_BDLO12> and
  *      multi_exp_with_mixed_addition (A/H/L queries), and the G2 half of

@@ -181,6 +181,123 @@ def domain_fft(a, inverse=False, coset=False, naive=False):
     return out
 
 
+# ---------------------------------------------------------------- evaluation-domain choice and step_radix2_domain
+def ceil_log2(n):
+    return (n - 1).bit_length() if n > 1 else 0
+
+
+def evaluation_domain(min_size):
+    """libfqfft get_evaluation_domain(min_size) for sizes up to 2^28 -> ('basic', m) or ('step', m).
+    [UPSTREAM-RECALL] order of attempts: basic_radix2(min_size), extended_radix2(min_size) (only when
+    log m = s + 1, never here), step_radix2(min_size), then the same three on big + rounded_small."""
+    assert min_size > 1
+    lg = ceil_log2(min_size)
+    if min_size == 1 << lg:
+        return ('basic', min_size)
+    big = 1 << (lg - 1); small = min_size - big
+    rounded_small = 1 << ceil_log2(small)
+    if small == rounded_small:
+        return ('step', min_size)
+    if big == rounded_small:
+        return ('basic', big + rounded_small)
+    return ('step', big + rounded_small)
+
+
+class Domain:
+    """An evaluation domain as a LIST OF POINTS; every operation below is the textbook definition
+    (evaluate / interpolate / product), not libfqfft's algorithm.
+    basic_radix2_domain(m): x_i = omega_m^i.
+    step_radix2_domain(m), m = big + small, big = 2^(ceil_log2(m)-1), small a power of two
+    [UPSTREAM-RECALL get_domain_element]: x_i = (omega^2)^i for i < big, omega * omega_small^(i-big)
+    after that, with omega = get_root_of_unity(2 big) and omega_small = get_root_of_unity(small)."""
+
+    def __init__(self, kind, m):
+        self.kind, self.m = kind, m
+        if kind == 'basic':
+            w = omega(ceil_log2(m))
+            self.points = [pow(w, i, R) for i in range(m)]
+        else:
+            lg = ceil_log2(m)
+            self.big = 1 << (lg - 1); self.small = m - self.big
+            assert self.small == 1 << ceil_log2(self.small)
+            w = omega(lg); ws = omega(ceil_log2(self.small))
+            self.omega = w
+            self.points = [pow(w, 2 * i, R) for i in range(self.big)] + [w * pow(ws, i, R) % R for i in range(self.small)]
+        assert len(set(self.points)) == m
+
+    @staticmethod
+    def for_size(min_size):
+        return Domain(*evaluation_domain(min_size))
+
+    def Z(self, t):
+        z = 1
+        for x in self.points:
+            z = z * (t - x) % R
+        return z
+
+    def Z_poly(self):
+        """coefficients of prod (X - x_i), low to high (monic, degree m)."""
+        c = [1]
+        for x in self.points:
+            nc = [0] * (len(c) + 1)
+            for i, v in enumerate(c):
+                nc[i + 1] = (nc[i + 1] + v) % R
+                nc[i] = (nc[i] - v * x) % R
+            c = nc
+        return c
+
+    def lagrange_at(self, t):
+        out = []
+        for i, xi in enumerate(self.points):
+            num = den = 1
+            for j, xj in enumerate(self.points):
+                if j != i:
+                    num = num * (t - xj) % R; den = den * (xi - xj) % R
+            out.append(num * inv(den, R) % R)
+        return out
+
+    def evaluate(self, coeffs):           # FFT: coefficients -> values on the domain
+        assert len(coeffs) == self.m
+        out = []
+        for x in self.points:
+            acc = 0
+            for c in reversed(coeffs):
+                acc = (acc * x + c) % R
+            out.append(acc)
+        return out
+
+    def interpolate(self, values):        # iFFT: values -> coefficients (degree < m)
+        assert len(values) == self.m
+        zp = self.Z_poly()
+        out = [0] * self.m
+        for xi, v in zip(self.points, values):
+            # q = Z / (X - xi) by synthetic division; L_i = q / q(xi)
+            q = [0] * self.m
+            carry = 0
+            for k in range(self.m, 0, -1):
+                carry = (zp[k] + carry * xi) % R
+                q[k - 1] = carry
+            qx = 0
+            for c in reversed(q):
+                qx = (qx * xi + c) % R
+            f = v * inv(qx, R) % R
+            for k in range(self.m):
+                out[k] = (out[k] + f * q[k]) % R
+        return out
+
+    def fft(self, a, inverse=False, coset=False):
+        """FFT / iFFT / cosetFFT(g) / icosetFFT(g), g = Fr::multiplicative_generator, by definition."""
+        if not inverse:
+            if coset:
+                a = [x * pow(FR_GEN, i, R) % R for i, x in enumerate(a)]
+            return self.evaluate(a)
+        out = self.interpolate(a)
+        if coset:
+            ginv = inv(FR_GEN, R)
+            out = [x * pow(ginv, i, R) % R for i, x in enumerate(out)]
+        return out
+
+
 # ---------------------------------------------------------------- R1CS / QAP / Groth16
 class R1CS:
     """rows: list of (a, b, c); each a dict {var_index: coeff}, index 0 = constant one,
@@ -189,17 +306,9 @@ class R1CS:
     def __init__(self, num_variables, num_inputs, rows):
         self.n, self.l, self.rows = num_variables, num_inputs, rows
 
-    def domain_log(self):
-        """libfqfft get_evaluation_domain(C + l + 1), restricted to the basic_radix2 outcomes."""
-        need = len(self.rows) + self.l + 1
-        lg = (need - 1).bit_length()
-        if need == 1 << lg:
-            return lg
-        big = 1 << (lg - 1); small = need - big
-        rounded_small = 1 << (small - 1).bit_length()
-        if small == rounded_small or big != rounded_small:
-            raise ValueError("libfqfft would pick step_radix2_domain for size %d" % need)
-        return lg
+    def domain(self):
+        """libfqfft get_evaluation_domain(C + l + 1) as r1cs_to_qap_instance_map asks for it."""
+        return Domain.for_size(len(self.rows) + self.l + 1)
 
     def is_satisfied(self, w):
         z = [1] + list(w)
@@ -228,8 +337,9 @@ def lagrange_at(m, t):
 
 
 def qap_evaluate(cs, t):
-    m = 1 << cs.domain_log()
-    u = lagrange_at(m, t)
+    dom = cs.domain()
+    m = dom.m
+    u = lagrange_at(m, t) if dom.kind == 'basic' else dom.lagrange_at(t)
     At = [0] * (cs.n + 1); Bt = [0] * (cs.n + 1); Ct = [0] * (cs.n + 1)
     C = len(cs.rows)
     for i in range(cs.l + 1):
@@ -238,7 +348,7 @@ def qap_evaluate(cs, t):
         for k, v in a.items(): At[k] = (At[k] + u[i] * v) % R
         for k, v in b.items(): Bt[k] = (Bt[k] + u[i] * v) % R
         for k, v in c.items(): Ct[k] = (Ct[k] + u[i] * v) % R
-    Zt = (pow(t, m, R) - 1) % R
+    Zt = (pow(t, m, R) - 1) % R if dom.kind == 'basic' else dom.Z(t)
     return m, At, Bt, Ct, Zt
 
 
@@ -265,8 +375,9 @@ def groth16_setup(cs, t, alpha, beta, gamma, delta, k1=1, k2=1):
 
 
 def qap_witness_h(cs, w):
-    """coefficients_for_H by polynomial long division (definition, not FFTs)."""
-    m = 1 << cs.domain_log()
+    """coefficients_for_H by interpolation and polynomial long division (definition, not FFTs)."""
+    dom = cs.domain()
+    m = dom.m
     C = len(cs.rows)
     z = [1] + list(w)
     ev = lambda lc: sum(c * z[i] for i, c in lc.items()) % R
@@ -275,7 +386,12 @@ def qap_witness_h(cs, w):
         aA[C + i] = z[i]
     for i, (a, b, c) in enumerate(cs.rows):
         aA[i] = (aA[i] + ev(a)) % R; aB[i] = ev(b); aC[i] = ev(c)
-    pa = domain_fft(aA, inverse=True); pb = domain_fft(aB, inverse=True); pc = domain_fft(aC, inverse=True)
+    if dom.kind == 'basic':
+        pa = domain_fft(aA, inverse=True); pb = domain_fft(aB, inverse=True); pc = domain_fft(aC, inverse=True)
+        zp = [R - 1] + [0] * (m - 1) + [1]
+    else:
+        pa = dom.interpolate(aA); pb = dom.interpolate(aB); pc = dom.interpolate(aC)
+        zp = dom.Z_poly()
     prod = [0] * (2 * m - 1)
     for i, x in enumerate(pa):
         if x:
@@ -283,14 +399,15 @@ def qap_witness_h(cs, w):
                 prod[i + j] = (prod[i + j] + x * y) % R
     for i, x in enumerate(pc):
         prod[i] = (prod[i] - x) % R
-    # divide by Z(X) = X^m - 1
+    # divide by the (monic) vanishing polynomial Z(X)
     h = [0] * (m - 1)
     rem = list(prod)
     for k in range(2 * m - 2, m - 1, -1):
         c = rem[k]
         h[k - m] = c
-        rem[k] = 0
-        rem[k - m] = (rem[k - m] + c) % R
+        if c:
+            for j in range(m + 1):
+                rem[k - m + j] = (rem[k - m + j] - c * zp[j]) % R
     assert all(v == 0 for v in rem), "witness does not satisfy the QAP"
     return h + [0, 0]        # m+1 coefficients like libsnark's coefficients_for_H
 

@@ -295,18 +295,140 @@ static void divide_by_Z_on_coset(Fr *a, size_t n) {
     Fr zinv = (coset_gen().pow_u64(n) - Fr::one()).inverse();
     for (size_t i = 0; i < n; ++i) a[i] *= zinv;
 }
-/* libfqfft get_evaluation_domain: returns m if the rule selects basic_radix2_domain, else 0.
- * (step/extended/geometric/arithmetic domains are outside the north-star path.) */
-static size_t evaluation_domain_size(size_t min_size) {
-    if (min_size <= 1) return 0;
+/* libfqfft get_evaluation_domain(min_size) for min_size <= 2^28: the order of attempts is basic_radix2(min_size),
+ * extended_radix2(min_size) (needs log m = s + 1: never here), step_radix2(min_size), then the same three on
+ * big + rounded_small.  [UPSTREAM-RECALL]  step = true <=> step_radix2_domain. */
+struct Domain {
+    size_t m = 0; bool step = false;
+    size_t big_m = 0, small_m = 0;            /* step_radix2_domain members */
+    Fr omega, big_omega, small_omega;
+};
+static bool make_domain(size_t min_size, Domain &d) {
+    if (min_size <= 1) return false;
     size_t lg = ceil_log2(min_size);
-    if (min_size == ((size_t)1 << lg)) return lg <= (size_t)FR_S ? min_size : 0;
-    size_t big = (size_t)1 << (lg - 1), small = min_size - big;
-    size_t rounded_small = (size_t)1 << ceil_log2(small);
-    if (small == rounded_small) return 0;            /* step_radix2_domain(min_size) would be chosen */
-    if (big == rounded_small) return lg <= (size_t)FR_S ? big + rounded_small : 0;
-    return 0;                                        /* step_radix2_domain(big + rounded_small)      */
+    if (lg > (size_t)FR_S) return false;
+    size_t m; bool step;
+    if (min_size == ((size_t)1 << lg)) { m = min_size; step = false; }
+    else {
+        size_t big = (size_t)1 << (lg - 1), small = min_size - big;
+        size_t rounded_small = (size_t)1 << ceil_log2(small);
+        if (small == rounded_small) { m = min_size; step = true; }
+        else if (big == rounded_small) { m = big + rounded_small; step = false; }
+        else { m = big + rounded_small; step = true; }
+    }
+    d.m = m; d.step = step;
+    if (!step) { d.omega = get_root_of_unity(m); return true; }
+    /* step_radix2_domain(m): big_m = 2^(log2(m)-1), small_m = m - big_m, omega = root of unity of order 2^log2(m) */
+    d.big_m = (size_t)1 << (ceil_log2(m) - 1); d.small_m = m - d.big_m;
+    d.omega = get_root_of_unity((size_t)1 << ceil_log2(m));
+    d.big_omega = d.omega.sqr();
+    d.small_omega = get_root_of_unity(d.small_m);
+    return true;
 }
+static size_t evaluation_domain_size(size_t min_size) { Domain d; return make_domain(min_size, d) ? d.m : 0; }
+
+/* step_radix2_domain::FFT: the polynomial is reduced mod (x^big - 1) (vector c) and, after the substitution
+ * x -> omega x, mod (x^small - 1) (vector e); one radix-2 FFT each */
+static void step_FFT(const Domain &D, Fr *a) {
+    const size_t big = D.big_m, small = D.small_m;
+    std::vector<Fr> c(big, Fr::zero()), d(big, Fr::zero());
+    Fr omega_i = Fr::one();
+    for (size_t i = 0; i < big; ++i) {
+        c[i] = (i < small ? a[i] + a[i + big] : a[i]);
+        d[i] = omega_i * (i < small ? a[i] - a[i + big] : a[i]);
+        omega_i *= D.omega;
+    }
+    std::vector<Fr> e(small, Fr::zero());
+    const size_t compr = (size_t)1 << (ceil_log2(big) - ceil_log2(small));
+    for (size_t i = 0; i < small; ++i)
+        for (size_t j = 0; j < compr; ++j) e[i] += d[i + j * small];
+    serial_radix2_fft(c.data(), big, D.omega.sqr());
+    if (small > 1) serial_radix2_fft(e.data(), small, get_root_of_unity(small));
+    for (size_t i = 0; i < big; ++i) a[i] = c[i];
+    for (size_t i = 0; i < small; ++i) a[i + big] = e[i];
+}
+/* step_radix2_domain::iFFT */
+static void step_iFFT(const Domain &D, Fr *a) {
+    const size_t big = D.big_m, small = D.small_m;
+    std::vector<Fr> U0(a, a + big), U1(a + big, a + big + small);
+    serial_radix2_fft(U0.data(), big, D.omega.sqr().inverse());
+    if (small > 1) serial_radix2_fft(U1.data(), small, get_root_of_unity(small).inverse());
+    const Fr U0_size_inv = Fr::from_u64(big).inverse();
+    for (size_t i = 0; i < big; ++i) U0[i] *= U0_size_inv;
+    const Fr U1_size_inv = Fr::from_u64(small).inverse();
+    for (size_t i = 0; i < small; ++i) U1[i] *= U1_size_inv;
+    std::vector<Fr> tmp = U0;
+    Fr omega_i = Fr::one();
+    for (size_t i = 0; i < big; ++i) { tmp[i] *= omega_i; omega_i *= D.omega; }
+    for (size_t i = small; i < big; ++i) a[i] = U0[i];                       /* save A_suffix */
+    const size_t compr = (size_t)1 << (ceil_log2(big) - ceil_log2(small));
+    for (size_t i = 0; i < small; ++i)
+        for (size_t j = 1; j < compr; ++j) U1[i] = U1[i] - tmp[i + j * small];
+    const Fr omega_inv = D.omega.inverse();
+    Fr omega_inv_i = Fr::one();
+    for (size_t i = 0; i < small; ++i) { U1[i] *= omega_inv_i; omega_inv_i *= omega_inv; }
+    const Fr over_two = Fr::from_u64(2).inverse();
+    for (size_t i = 0; i < small; ++i) a[i] = (U0[i] + U1[i]) * over_two;   /* A_prefix */
+    for (size_t i = 0; i < small; ++i) a[big + i] = (U0[i] - U1[i]) * over_two;   /* B2 */
+}
+/* step_radix2_domain::divide_by_Z_on_coset, Z(x) = (x^big - 1)(x^small - omega^small) */
+static void step_divide_by_Z_on_coset(const Domain &D, Fr *P) {
+    const size_t big = D.big_m, small = D.small_m;
+    const Fr coset = coset_gen();
+    const Fr Z0 = coset.pow_u64(big) - Fr::one();
+    const Fr coset_to_small_m_times_Z0 = coset.pow_u64(small) * Z0;
+    const Fr omega_to_small_m_times_Z0 = D.omega.pow_u64(small) * Z0;
+    const Fr omega_to_2small_m = D.omega.pow_u64(2 * small);
+    Fr elt = Fr::one();
+    for (size_t i = 0; i < big; ++i) {
+        P[i] *= (coset_to_small_m_times_Z0 * elt - omega_to_small_m_times_Z0).inverse();
+        elt *= omega_to_2small_m;
+    }
+    const Fr co = coset * D.omega;
+    const Fr Z1 = (co.pow_u64(big) - Fr::one()) * (co.pow_u64(small) - D.omega.pow_u64(small));
+    const Fr Z1_inverse = Z1.inverse();
+    for (size_t i = 0; i < small; ++i) P[big + i] *= Z1_inverse;
+}
+/* _basic_radix2_evaluate_all_lagrange_polynomials(m, t) */
+static std::vector<Fr> basic_lagrange(size_t m, const Fr &t) {
+    std::vector<Fr> u(m, Fr::zero());
+    if (m == 1) { u[0] = Fr::one(); return u; }
+    const Fr omega = get_root_of_unity(m);
+    if (t.pow_u64(m) == Fr::one()) {                       /* t is in the domain: a unit vector */
+        Fr omega_i = Fr::one();
+        for (size_t i = 0; i < m; ++i) { if (omega_i == t) { u[i] = Fr::one(); return u; } omega_i *= omega; }
+    }
+    const Fr Z = t.pow_u64(m) - Fr::one();
+    Fr l = Z * Fr::from_u64(m).inverse(), r = Fr::one();
+    for (size_t i = 0; i < m; ++i) { u[i] = l * (t - r).inverse(); l *= omega; r *= omega; }
+    return u;
+}
+/* evaluate_all_lagrange_polynomials(t) of the chosen domain */
+static std::vector<Fr> domain_lagrange(const Domain &D, const Fr &t) {
+    if (!D.step) return basic_lagrange(D.m, t);
+    const size_t big = D.big_m, small = D.small_m;
+    std::vector<Fr> inner_big = basic_lagrange(big, t), inner_small = basic_lagrange(small, t * D.omega.inverse());
+    std::vector<Fr> result(D.m, Fr::zero());
+    const Fr omega_to_small_m = D.omega.pow_u64(small);
+    const Fr L0 = t.pow_u64(small) - omega_to_small_m;
+    const Fr big_omega_to_small_m = D.big_omega.pow_u64(small);
+    Fr elt = Fr::one();
+    for (size_t i = 0; i < big; ++i) { result[i] = inner_big[i] * L0 * (elt - omega_to_small_m).inverse(); elt *= big_omega_to_small_m; }
+    const Fr L1 = (t.pow_u64(big) - Fr::one()) * (D.omega.pow_u64(big) - Fr::one()).inverse();
+    for (size_t i = 0; i < small; ++i) result[big + i] = L1 * inner_small[i];
+    return result;
+}
+/* compute_vanishing_polynomial(t) */
+static Fr domain_vanishing(const Domain &D, const Fr &t) {
+    if (!D.step) return t.pow_u64(D.m) - Fr::one();
+    return (t.pow_u64(D.big_m) - Fr::one()) * (t.pow_u64(D.small_m) - D.omega.pow_u64(D.small_m));
+}
+/* the four transforms on whichever domain was chosen (a has D.m entries) */
+static void dom_FFT(const Domain &D, Fr *a) { if (D.step) step_FFT(D, a); else domain_FFT(a, D.m); }
+static void dom_iFFT(const Domain &D, Fr *a) { if (D.step) step_iFFT(D, a); else domain_iFFT(a, D.m); }
+static void dom_cosetFFT(const Domain &D, Fr *a, const Fr &g) { multiply_by_coset(a, D.m, g); dom_FFT(D, a); }
+static void dom_icosetFFT(const Domain &D, Fr *a, const Fr &g) { dom_iFFT(D, a); multiply_by_coset(a, D.m, g.inverse()); }
+static void dom_divide_by_Z_on_coset(const Domain &D, Fr *a) { if (D.step) step_divide_by_Z_on_coset(D, a); else divide_by_Z_on_coset(a, D.m); }
 
 /* ------------------------------------------------------------------ libff multi_exp_inner<T, FieldT, multi_exp_method_BDLO12> */
 static inline bool test_bit(const u64 *k, size_t b) { return b < 256 && ((k[b / 64] >> (b % 64)) & 1); }
@@ -410,8 +532,9 @@ static std::vector<Fr> padded_assignment(const zkg_r1cs &cs, const u64 *w) {
 
 /* libsnark r1cs_to_qap_witness_map(cs, primary, auxiliary, 0, 0, 0) -> coefficients_for_H[m+1] */
 static int qap_witness_map(const zkg_r1cs &cs, const u64 *w, std::vector<Fr> &H, size_t &m_out) {
-    size_t m = evaluation_domain_size((size_t)cs.num_constraints + cs.num_inputs + 1);
-    if (!m) return 1;
+    Domain D;
+    if (!make_domain((size_t)cs.num_constraints + cs.num_inputs + 1, D)) return 1;
+    const size_t m = D.m;
     m_out = m;
     std::vector<Fr> z = padded_assignment(cs, w);
     std::vector<Fr> aA(m, Fr::zero()), aB(m, Fr::zero());
@@ -420,17 +543,17 @@ static int qap_witness_map(const zkg_r1cs &cs, const u64 *w, std::vector<Fr> &H,
         aA[i] += row_eval(cs.a_rowptr, cs.a_col, cs.a_val, i, z);
         aB[i] += row_eval(cs.b_rowptr, cs.b_col, cs.b_val, i, z);
     }
-    domain_iFFT(aA.data(), m); domain_iFFT(aB.data(), m);
+    dom_iFFT(D, aA.data()); dom_iFFT(D, aB.data());
     Fr g = coset_gen();
-    domain_cosetFFT(aA.data(), m, g); domain_cosetFFT(aB.data(), m, g);
+    dom_cosetFFT(D, aA.data(), g); dom_cosetFFT(D, aB.data(), g);
     std::vector<Fr> &H_tmp = aA;
     for (size_t i = 0; i < m; ++i) H_tmp[i] = aA[i] * aB[i];
     std::vector<Fr> aC(m, Fr::zero());
     for (u32 i = 0; i < cs.num_constraints; ++i) aC[i] += row_eval(cs.c_rowptr, cs.c_col, cs.c_val, i, z);
-    domain_iFFT(aC.data(), m); domain_cosetFFT(aC.data(), m, g);
+    dom_iFFT(D, aC.data()); dom_cosetFFT(D, aC.data(), g);
     for (size_t i = 0; i < m; ++i) H_tmp[i] = H_tmp[i] - aC[i];
-    divide_by_Z_on_coset(H_tmp.data(), m);
-    domain_icosetFFT(H_tmp.data(), m, g);
+    dom_divide_by_Z_on_coset(D, H_tmp.data());
+    dom_icosetFFT(D, H_tmp.data(), g);
     H.assign(m + 1, Fr::zero());
     for (size_t i = 0; i < m; ++i) H[i] = H_tmp[i];
     return 0;
@@ -544,6 +667,24 @@ int zko_fft(u64 *a, unsigned logn, int inverse, int coset) {
     return 0;
 }
 size_t zko_evaluation_domain_size(size_t min_size) { return evaluation_domain_size(min_size); }
+int zko_evaluation_domain_is_step(size_t min_size) { Domain d; return make_domain(min_size, d) && d.step; }
+/* the same four transforms on get_evaluation_domain(m) for an m the rule maps to itself (a power of two or 2^a + 2^b) */
+int zko_domain_fft(u64 *a, size_t m, int inverse, int coset) {
+    Domain D; if (!make_domain(m, D) || D.m != m) return 1;
+    Fr *v = reinterpret_cast<Fr *>(a); Fr g = coset_gen();
+    if (!inverse) { if (coset) dom_cosetFFT(D, v, g); else dom_FFT(D, v); }
+    else { if (coset) dom_icosetFFT(D, v, g); else dom_iFFT(D, v); }
+    return 0;
+}
+/* evaluate_all_lagrange_polynomials(t) (out: m Montgomery Fr) and compute_vanishing_polynomial(t); t canonical limbs */
+int zko_domain_lagrange(size_t m, const u64 t_[4], u64 *out, u64 *z_out) {
+    Domain D; if (!make_domain(m, D) || D.m != m) return 1;
+    Fr t = Fr::from_canonical(t_);
+    std::vector<Fr> u = domain_lagrange(D, t);
+    memcpy(out, u.data(), m * 32);
+    Fr z = domain_vanishing(D, t); memcpy(z_out, z.v, 32);
+    return 0;
+}
 
 /* method: 0 naive double-and-add, 1 BDLO12 bucket method (chunks = threads), 2 multi_exp_with_mixed_addition */
 int zko_msm_g1(const u64 *bases, const u64 *scalars, size_t n, u64 out[12], int method, int chunks) {
@@ -574,7 +715,7 @@ int zko_groth16_prove(const zkg_pk *pk, const u64 *w, const u64 r_[4], const u64
     if (check_satisfied && !zko_r1cs_is_satisfied(&cs, w)) return ZKG_UNSATISFIED;
     std::vector<Fr> H; size_t m;
     if (qap_witness_map(cs, w, H, m)) return 2;
-    if (m != ((size_t)1 << pk->log_m)) return 2;
+    if (m != (pk->domain_size ? (size_t)pk->domain_size : ((size_t)1 << pk->log_m))) return 2;
     Fr r = Fr::from_limbs(r_), s = Fr::from_limbs(s_);
     size_t n = cs.num_variables, l = cs.num_inputs;
     std::vector<u64> zc((n + 1) * 4), hc((m - 1) * 4);           /* as_bigint() of the scalars */
@@ -605,17 +746,13 @@ int zko_groth16_prove(const zkg_pk *pk, const u64 *w, const u64 r_[4], const u64
  * Also emits the QAP evaluations At/Bt/Ct (n+1 Montgomery Fr each) and Zt for known-trapdoor checks. */
 int zko_groth16_setup(const zkg_r1cs *cs, const u64 *td, u64 *alpha_g1, u64 *beta_g1, u64 *delta_g1, u64 *beta_g2, u64 *delta_g2,
                       u64 *A_query, u64 *B_g1, u64 *B_g2, u64 *H_query, u64 *L_query, u64 *At_out, u64 *Bt_out, u64 *Ct_out, u64 *Zt_out) {
-    size_t m = evaluation_domain_size((size_t)cs->num_constraints + cs->num_inputs + 1);
-    if (!m) return 1;
+    Domain D;
+    if (!make_domain((size_t)cs->num_constraints + cs->num_inputs + 1, D)) return 1;
+    size_t m = D.m;
     size_t n = cs->num_variables, l = cs->num_inputs, C = cs->num_constraints;
     Fr t = Fr::from_canonical(td), alpha = Fr::from_canonical(td + 4), beta = Fr::from_canonical(td + 8), delta = Fr::from_canonical(td + 16);
-    /* evaluate_all_lagrange_polynomials(t) (basic_radix2_domain): u[i] = Z(t) * omega^i / (m (t - omega^i)) */
-    Fr Zt = t.pow_u64(m) - Fr::one();
-    std::vector<Fr> u(m);
-    {
-        Fr omega = get_root_of_unity(m), wi = Fr::one(), minv = Fr::from_u64(m).inverse();
-        for (size_t i = 0; i < m; ++i) { u[i] = Zt * wi * minv * (t - wi).inverse(); wi *= omega; }
-    }
+    Fr Zt = domain_vanishing(D, t);
+    std::vector<Fr> u = domain_lagrange(D, t);
     std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
     for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
     for (size_t i = 0; i < C; ++i) {
@@ -654,7 +791,7 @@ size_t zko_pk_write_blob(const zkg_pk *pk, uint8_t *out, size_t cap) {
     auto g1 = [&](const u64 *p) { uint8_t t[34]; ser_g1(t, G1::from_affine(load_g1(p))); buf.insert(buf.end(), t, t + 34); };
     auto g2 = [&](const u64 *p) { uint8_t t[66]; ser_g2(t, G2::from_affine(load_g2(p))); buf.insert(buf.end(), t, t + 66); };
     const zkg_r1cs &cs = pk->cs;
-    size_t n = cs.num_variables, l = cs.num_inputs, m = (size_t)1 << pk->log_m;
+    size_t n = cs.num_variables, l = cs.num_inputs, m = pk->domain_size ? (size_t)pk->domain_size : ((size_t)1 << pk->log_m);
     g1(pk->alpha_g1); g1(pk->beta_g1); g2(pk->beta_g2); g1(pk->delta_g1); g2(pk->delta_g2);
     dec(n + 1); for (size_t i = 0; i <= n; ++i) g1(pk->A_query + 8 * i);
     std::vector<size_t> idx;

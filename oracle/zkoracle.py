@@ -25,7 +25,7 @@ class R1CS(C.Structure):
 
 
 class PK(C.Structure):
-    _fields_ = [("cs", R1CS), ("log_m", C.c_uint32), ("reserved", C.c_uint32)] + \
+    _fields_ = [("cs", R1CS), ("log_m", C.c_uint32), ("domain_size", C.c_uint32)] + \
         [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query")]
 
 
@@ -110,11 +110,22 @@ def g2_fixed_base(base, scalars):
 
 
 def fft(a, inverse=False, coset=False):
+    """FFT / iFFT / cosetFFT / icosetFFT on get_evaluation_domain(n): n a power of two (basic_radix2_domain) or
+    2^a + 2^b (step_radix2_domain)"""
     a = u64(a).copy(); n = a.size // 4
     logn = n.bit_length() - 1
-    assert 1 << logn == n
-    assert lib().zko_fft(_p(a), logn, int(inverse), int(coset)) == 0
+    if 1 << logn == n:
+        assert lib().zko_fft(_p(a), logn, int(inverse), int(coset)) == 0
+    else:
+        assert lib().zko_domain_fft(_p(a), C.c_size_t(n), int(inverse), int(coset)) == 0, "not a step_radix2 size"
     return a.reshape(n, 4)
+
+
+def domain_lagrange(m, t_canonical):
+    """evaluate_all_lagrange_polynomials(t) and compute_vanishing_polynomial(t) -> ((m,4) Montgomery, (4,) Montgomery)"""
+    out = np.zeros((m, 4), np.uint64); z = np.zeros(4, np.uint64)
+    assert lib().zko_domain_lagrange(C.c_size_t(m), _p(u64(t_canonical)), _p(out), _p(z)) == 0
+    return out, z
 
 
 NAIVE, BDLO12, MIXED = 0, 1, 2
@@ -134,6 +145,10 @@ def msm_g2(bases, scalars, method=BDLO12, chunks=1):
 
 def evaluation_domain_size(min_size):
     return int(lib().zko_evaluation_domain_size(min_size))
+
+
+def evaluation_domain_is_step(min_size):
+    return bool(lib().zko_evaluation_domain_is_step(C.c_size_t(min_size)))
 
 
 def make_r1cs(n, l, A, B, Cm, keep):
@@ -161,7 +176,7 @@ def groth16_setup(cs, td_canonical):
     """td: 5x4 canonical limbs (t, alpha, beta, gamma, delta).  Returns dict of arrays + a PK struct."""
     n, l = cs.num_variables, cs.num_inputs
     m = evaluation_domain_size(cs.num_constraints + l + 1)
-    assert m, "domain is not basic_radix2"
+    assert m, "no radix-2 or step domain of that size"
     z = lambda *s: np.zeros(s, np.uint64)
     d = dict(alpha_g1=z(8), beta_g1=z(8), delta_g1=z(8), beta_g2=z(16), delta_g2=z(16), A_query=z(n + 1, 8), B_g1=z(n + 1, 8),
              B_g2=z(n + 1, 16), H_query=z(m - 1, 8), L_query=z(n - l, 8), At=z(n + 1, 4), Bt=z(n + 1, 4), Ct=z(n + 1, 4), Zt=z(4))
@@ -176,7 +191,8 @@ def groth16_setup(cs, td_canonical):
 def make_pk(cs, crs):
     pk = PK()
     pk.cs = cs
-    pk.log_m = crs["m"].bit_length() - 1
+    pk.log_m = (crs["m"] - 1).bit_length()
+    pk.domain_size = crs["m"]
     for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query"):
         setattr(pk, k, crs[k].ctypes.data)
     return pk

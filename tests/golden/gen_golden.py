@@ -115,9 +115,9 @@ def random_r1cs(n_in, n_free, n_mul, bits_frac=0.5):
     return P.R1CS(len(vals), l, rows), vals
 
 
-def gen_groth16():
+def groth16_cases(shapes):
     out = []
-    for (n_in, n_free, n_mul, tag) in ((1, 2, 5, "tiny"), (2, 5, 13, "m16"), (3, 6, 27, "m32_exact_fill"), (41 % 7, 9, 50, "m64")):
+    for (n_in, n_free, n_mul, tag) in shapes:
         cs, w = random_r1cs(n_in, n_free, n_mul)
         assert cs.is_satisfied(w)
         td = {k: rnd.randrange(1, P.R) for k in ("t", "alpha", "beta", "gamma", "delta")}
@@ -127,7 +127,7 @@ def gen_groth16():
         assert P.groth16_check_dlog(cs2, crs, w, r, s, proof=proof, **td)
         h = P.qap_witness_h(cs2, w)
         enc = lambda d: [[str(i), H(c)] for i, c in sorted(d.items())]
-        out.append(dict(tag=tag, num_variables=cs2.n, num_inputs=cs2.l, m=crs["m"],
+        out.append(dict(tag=tag, num_variables=cs2.n, num_inputs=cs2.l, m=crs["m"], domain=cs2.domain().kind,
                         rows=[[enc(a), enc(b), enc(c)] for a, b, c in cs2.rows],
                         trapdoor={k: H(v) for k, v in td.items()}, witness=[H(x) for x in w], r=H(r), s=H(s), h=[H(x) for x in h],
                         crs=dict(alpha_g1=pt1(crs["alpha_g1"]), beta_g1=pt1(crs["beta_g1"]), delta_g1=pt1(crs["delta_g1"]),
@@ -136,9 +136,37 @@ def gen_groth16():
                                  H=[pt1(p) for p in crs["H"]], L=[pt1(p) for p in crs["L"]]),
                         proof_points=dict(A=pt1(proof[0]), B=pt2(proof[1]), C=pt1(proof[2])),
                         proof_hex=P.ser_proof(proof).hex()))
-        print(tag, "n", cs2.n, "C", len(cs2.rows), "m", crs["m"])
-    dump("groth16.json", out)
+        print(tag, "n", cs2.n, "C", len(cs2.rows), "m", crs["m"], cs2.domain().kind)
+    return out
+
+
+def gen_groth16():
+    dump("groth16.json", groth16_cases(((1, 2, 5, "tiny"), (2, 5, 13, "m16"), (3, 6, 27, "m32_exact_fill"), (41 % 7, 9, 50, "m64"))))
+
+
+def gen_step_domain():
+    """step_radix2_domain (m = 2^a + 2^b): what libfqfft's get_evaluation_domain picks for 10 of zklaim's 20 payload
+    counts.  Everything from oracle/pyref.py's Domain class (points, naive evaluation, Lagrange interpolation)."""
+    out = {"rule": [[k, *P.evaluation_domain(k)] for k in list(range(2, 70)) + [82738, 137894, 165472, 275784, 303362, 330940, 551566, (1 << 18) - 3]],
+           "fft": [], "lagrange": []}
+    for m in (3, 5, 6, 10, 12, 20, 24, 48, 40, 36):
+        d = P.Domain.for_size(m)
+        assert d.kind == "step" and d.m == m
+        a = [rnd.randrange(P.R) for _ in range(m)]
+        if m == 12:
+            a[0], a[1], a[2], a[11] = 0, 1, P.R - 1, 0
+        case = dict(m=m, big=d.big, small=d.small, a=[H(x) for x in a], points=[H(x) for x in d.points])
+        for inv_ in (0, 1):
+            for coset in (0, 1):
+                case[f"out_inv{inv_}_coset{coset}"] = [H(x) for x in d.fft(a, inverse=bool(inv_), coset=bool(coset))]
+        out["fft"].append(case)
+        t = rnd.randrange(P.R)
+        out["lagrange"].append(dict(m=m, t=H(t), u=[H(x) for x in d.lagrange_at(t)], Z=H(d.Z(t))))
+    dump("step_domain.json", out)
+    # need = C + l + 1: 5+1+1 = 7 -> basic 8 (control); 8+1+1 = 10 -> step 10; 7+2+1=10; 14+2+1 = 17 -> step 17 (16+1);
+    # 17+3+1 = 21 -> step 24; 40+2+1 = 43 -> step 48
+    dump("groth16_step.json", groth16_cases(((1, 2, 8, "step10"), (2, 3, 14, "step17"), (3, 4, 17, "step24_from21"), (2, 6, 40, "step48_from43"))))
 
 
 if __name__ == "__main__":
-    gen_field(); gen_curve(); gen_ntt(); gen_msm(); gen_groth16()
+    gen_field(); gen_curve(); gen_ntt(); gen_msm(); gen_groth16(); gen_step_domain()

@@ -1,0 +1,134 @@
+"""GPU parity on libfqfft's step_radix2_domain (m = 2^a + 2^b), the domain get_evaluation_domain(C + l + 1) picks for 10 of
+zklaim's 20 payload counts (3, 5, 6, 7, 10-14, 20): transforms against the definition-level golden vectors and the oracle's
+restatement, the prover and the generator on step-domain systems (proof and key bytes identical), the 3-payload zklaim
+credential end to end."""
+import numpy as np
+import pytest
+
+from gpu_util import zkg  # noqa: F401
+from r1cs_util import golden_case_arrays
+from util import R, arr, golden, h, ints, random_fr_canonical
+
+pytestmark = pytest.mark.gpu
+STEP = golden("step_domain.json")
+CASES = golden("groth16_step.json")
+
+
+def test_domain_rule(zkg):
+    for k, kind, m in STEP["rule"]:
+        assert zkg.evaluation_domain_size(k) == (m, kind == "step"), k
+    with pytest.raises(zkg.ZkgError):
+        zkg.evaluation_domain_size((1 << 28) + 1)
+
+
+def test_step_ntt_golden(zkg):
+    for c in STEP["fft"]:
+        a = arr([h(x) for x in c["a"]], R)
+        for inv in (0, 1):
+            for coset in (0, 1):
+                out = zkg.ntt(a, inverse=inv, coset=coset)
+                assert ints(out, R) == [h(x) for x in c[f"out_inv{inv}_coset{coset}"]], (c["m"], inv, coset)
+
+
+@pytest.mark.parametrize("a_log,b_log", [(10, 3), (11, 10), (12, 0), (13, 12), (16, 12), (17, 13)])
+def test_step_ntt_vs_oracle(zkg, oracle, a_log, b_log):
+    m = (1 << a_log) + (1 << b_log)
+    a = random_fr_canonical(m, 0x57E9 + m)          # any 4-limb values < r serve as Montgomery representations
+    for inv in (0, 1):
+        for coset in (0, 1):
+            assert np.array_equal(zkg.ntt(a, inverse=inv, coset=coset), oracle.fft(a, inverse=inv, coset=coset)), (m, inv, coset)
+
+
+def test_step_ntt_roundtrip_large(zkg):
+    """size-independent properties at 2^20 + 2^16: iFFT(FFT(a)) = a, icosetFFT(cosetFFT(a)) = a, FFT(a + b) = FFT(a) + FFT(b)"""
+    m = (1 << 20) + (1 << 16)
+    a = random_fr_canonical(m, 11); b = random_fr_canonical(m, 12)
+    fa, fb = zkg.ntt(a), zkg.ntt(b)
+    assert np.array_equal(zkg.ntt(fa, inverse=True), a)
+    assert np.array_equal(zkg.ntt(zkg.ntt(a, coset=True), inverse=True, coset=True), a)
+    add = lambda x, y: arr([(u + v) % R for u, v in zip(ints(x), ints(y))])
+    assert np.array_equal(zkg.ntt(add(a, b)), add(fa, fb))
+
+
+def test_not_a_domain_size_is_refused(zkg):
+    with pytest.raises(zkg.ZkgError):
+        zkg.ntt(random_fr_canonical(11, 1))          # 8 + 3: get_evaluation_domain would return 12, not 11
+    with pytest.raises(zkg.ZkgError):
+        zkg.ntt(random_fr_canonical(7, 1))           # 4 + 3 -> basic 8
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
+def test_prove_golden_step(zkg, case):
+    assert case["domain"] == "step"
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    cs = zkg.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
+    m = case["m"]
+    pk = zkg.make_pk(cs, pts, (m - 1).bit_length(), keep, domain_size=m)
+    crs = zkg.Crs(pk)
+    assert ints(crs.qap_witness_h(w), R) == [h(x) for x in case["h"]]
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    bad = w.copy(); bad[-1, 0] ^= np.uint64(1)
+    rc, _ = crs.prove(bad, r, s)
+    assert rc == 1
+    crs.free()
+    # a pk that claims the next power of two for a system stored with step-domain queries is inconsistent: H_query is too short
+    # for it, and the ABI has no way to see that, so the honest failure mode is a size mismatch on the blob path (below)
+
+
+@pytest.mark.parametrize("case", CASES[:3], ids=[c["tag"] for c in CASES[:3]])
+def test_setup_and_blob_step(zkg, oracle, case):
+    """generator on a step domain == definition-level golden key; blob round trip recovers the domain from |H_query| + 1"""
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    cs = zkg.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
+    td = arr([h(case["trapdoor"][k]) for k in ("t", "alpha", "beta", "gamma", "delta")])
+    kp = zkg.Keypair(cs, td)
+    n, l, m = case["num_variables"], case["num_inputs"], case["m"]
+    assert kp.pk.domain_size == m
+    for name, count, limbs_ in (("A_query", n + 1, 8), ("B_g1", n + 1, 8), ("B_g2", n + 1, 16), ("H_query", m - 1, 8), ("L_query", n - l, 8)):
+        assert np.array_equal(kp.array(name, count, limbs_).reshape(-1), pts[name].reshape(-1)), name
+    crs = zkg.Crs(blob=kp.pk_blob(), m=m)
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    assert zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
+    crs.free(); kp.free()
+    # the oracle's blob writer on the golden key gives the same prover input
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs2 = zkg.Crs(blob=oracle.pk_write_blob(oracle.make_pk(ocs, pts)), m=m)
+    rc, proof2 = crs2.prove(w, r, s)
+    assert rc == 0 and proof2 == proof
+    crs2.free()
+
+
+def test_prove_zklaim_three_payloads_vs_oracle(zkg, oracle):
+    """the reference's can_handle_three_payloads shape: C + l + 1 = 82738 -> step_radix2_domain(2^16 + 2^15).
+    Key from the GPU generator (known trapdoor), proof bytes GPU == oracle, verifier accepts."""
+    keep = []
+    pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i)
+           for i in range(3)]
+    ck = zkg.ZklaimCircuit(zkg.make_ctx(pls, keep))
+    assert ck.is_satisfied()
+    n, l = ck.r1cs.num_variables, ck.r1cs.num_inputs
+    assert zkg.evaluation_domain_size(ck.r1cs.num_constraints + l + 1) == ((1 << 16) + (1 << 15), True)
+    kp = zkg.Keypair(ck.r1cs, random_fr_canonical(5, 0x99))
+    m = kp.pk.domain_size
+    assert m == (1 << 16) + (1 << 15)
+    w = ck.witness()
+    crs = zkg.Crs(kp.pk)
+    rs = random_fr_canonical(2, 0x9A)
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc == 0 and zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
+    print("zklaim k=3 (m = 98304, step) prove stage ms", crs.stage_ms())
+    A, B, C = ck.csr()
+    if kp.swapped:
+        A, B = B, A
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    assert np.array_equal(crs.qap_witness_h(w), oracle.qap_witness_h(ocs, w, m))
+    arrays = {name: kp.array(name, cnt, lim) for name, cnt, lim in (("A_query", n + 1, 8), ("B_g1", n + 1, 8), ("B_g2", n + 1, 16), ("H_query", m - 1, 8),
+              ("L_query", n - l, 8), ("alpha_g1", 1, 8), ("beta_g1", 1, 8), ("delta_g1", 1, 8), ("beta_g2", 1, 16), ("delta_g2", 1, 16))}
+    arrays["m"] = m
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, arrays), w, rs[0], rs[1], chunks=oracle.num_threads())
+    assert rc_o == 0 and proof_o == proof
+    crs.free(); kp.free()

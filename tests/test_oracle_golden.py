@@ -104,9 +104,27 @@ def test_msm(oracle):
 
 
 def test_domain_rule(oracle):
-    # libfqfft get_evaluation_domain: basic_radix2 for powers of two and for big+rounded_small == 2*big
+    # libfqfft get_evaluation_domain: basic_radix2 for powers of two and for big + rounded_small == 2 big, step_radix2 otherwise
     assert oracle.evaluation_domain_size(32) == 32
     assert oracle.evaluation_domain_size(31) == 32      # big=16, small=15 -> rounded 16
-    assert oracle.evaluation_domain_size(24) == 0       # 16 + 8: step_radix2
-    assert oracle.evaluation_domain_size(21) == 0       # 16 + 5 -> 16 + 8: step_radix2
+    assert oracle.evaluation_domain_size(24) == 24 and oracle.evaluation_domain_is_step(24)      # 16 + 8
+    assert oracle.evaluation_domain_size(21) == 24 and oracle.evaluation_domain_is_step(21)      # 16 + 5 -> 16 + 8
     assert oracle.evaluation_domain_size((1 << 18) - 3) == 1 << 18
+    for k, kind, m in golden("step_domain.json")["rule"]:
+        assert oracle.evaluation_domain_size(k) == m and oracle.evaluation_domain_is_step(k) == (kind == "step"), k
+
+
+def test_step_domain_transforms(oracle):
+    """libfqfft's step_radix2_domain algorithms (restated in zkoracle.cpp) against the textbook definitions
+    (evaluation at the domain points / Lagrange interpolation) in tests/golden/step_domain.json"""
+    g = golden("step_domain.json")
+    for c in g["fft"]:
+        a = arr([h(x) for x in c["a"]], R)
+        for inv in (0, 1):
+            for coset in (0, 1):
+                out = oracle.fft(a, inverse=inv, coset=coset)
+                assert ints(out, R) == [h(x) for x in c[f"out_inv{inv}_coset{coset}"]], (c["m"], inv, coset)
+    for c in g["lagrange"]:
+        u, z = oracle.domain_lagrange(c["m"], limbs(h(c["t"])))
+        assert ints(u, R) == [h(x) for x in c["u"]], c["m"]
+        assert ints(z, R)[0] == h(c["Z"]), c["m"]

@@ -5,7 +5,8 @@ import pytest
 from r1cs_util import golden_case_arrays
 from util import R, arr, golden, h, ints
 
-CASES = golden("groth16.json")
+CASES = golden("groth16.json") + golden("groth16_step.json")      # basic_radix2 and step_radix2 domains
+SETUP_CASES = CASES[:3] + CASES[4:7]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
@@ -15,6 +16,7 @@ def test_prove_matches_definition(oracle, case):
     cs = oracle.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
     assert oracle.r1cs_is_satisfied(cs, w)
     assert oracle.evaluation_domain_size(cs.num_constraints + cs.num_inputs + 1) == case["m"]
+    assert oracle.evaluation_domain_is_step(cs.num_constraints + cs.num_inputs + 1) == (case["domain"] == "step")
     # coefficients_for_H == polynomial long division in pyref
     hh = oracle.qap_witness_h(cs, w, case["m"])
     assert ints(hh, R) == [h(x) for x in case["h"]]
@@ -30,7 +32,7 @@ def test_prove_matches_definition(oracle, case):
     assert rc3 == 1
 
 
-@pytest.mark.parametrize("case", CASES[:3], ids=[c["tag"] for c in CASES[:3]])
+@pytest.mark.parametrize("case", SETUP_CASES, ids=[c["tag"] for c in SETUP_CASES])
 def test_setup_matches_definition(oracle, case):
     A, B, C, pts, w, r, s = golden_case_arrays(case)
     keep = []

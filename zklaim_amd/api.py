@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libzkg.so")
 
 DECLARED_SYMBOLS = [
-    "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_msm_g1", "zkg_msm_g2",
+    "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_evaluation_domain_size", "zkg_ntt_domain", "zkg_ntt_domain_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
@@ -36,7 +36,7 @@ class R1CS(C.Structure):
 
 
 class PK(C.Structure):
-    _fields_ = [("cs", R1CS), ("log_m", C.c_uint32), ("reserved", C.c_uint32)] + \
+    _fields_ = [("cs", R1CS), ("log_m", C.c_uint32), ("domain_size", C.c_uint32)] + \
         [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query")]
 
 
@@ -109,12 +109,24 @@ def device_info():
 
 # ---- NTT (libfqfft basic_radix2_domain FFT/iFFT/cosetFFT/icosetFFT) -------------------------------
 def ntt(a, inverse=False, coset=False):
+    """FFT / iFFT / cosetFFT / icosetFFT on the domain get_evaluation_domain(len(a)) names: a power of two
+    (basic_radix2_domain, zkg_ntt) or 2^a + 2^b (step_radix2_domain, zkg_ntt_domain)"""
     a = _u64(a).copy(); n = a.size // 4
     logn = n.bit_length() - 1
-    if n == 0 or (1 << logn) != n:
-        raise ZkgError("ntt: length must be a power of two")
-    _check(lib().zkg_ntt(_p(a), C.c_uint(logn), int(inverse), int(coset)), "zkg_ntt")
+    if n == 0:
+        raise ZkgError("ntt: empty input")
+    if (1 << logn) == n:
+        _check(lib().zkg_ntt(_p(a), C.c_uint(logn), int(inverse), int(coset)), "zkg_ntt")
+    else:
+        _check(lib().zkg_ntt_domain(_p(a), C.c_size_t(n), int(inverse), int(coset)), "zkg_ntt_domain")
     return a.reshape(n, 4)
+
+
+def evaluation_domain_size(min_size):
+    """libfqfft get_evaluation_domain(min_size) -> (m, is_step)"""
+    m = C.c_size_t(0); st = C.c_int(0)
+    _check(lib().zkg_evaluation_domain_size(C.c_size_t(min_size), C.byref(m), C.byref(st)), "zkg_evaluation_domain_size")
+    return m.value, bool(st.value)
 
 
 def ntt_dev(d_ptr, logn, inverse=False, coset=False, stream=0):
@@ -190,8 +202,9 @@ def make_r1cs(n, l, A, B, Cm, keep):
     return cs
 
 
-def make_pk(cs, arrays, log_m, keep):
-    pk = PK(); pk.cs = cs; pk.log_m = log_m
+def make_pk(cs, arrays, log_m, keep, domain_size=0):
+    """domain_size: m when it is a step_radix2 size 2^(log_m-1) + 2^b; 0 for m = 2^log_m"""
+    pk = PK(); pk.cs = cs; pk.log_m = log_m; pk.domain_size = domain_size
     for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "A_query", "B_g1", "B_g2", "H_query", "L_query"):
         a = _u64(arrays[k]); keep.append(a)
         setattr(pk, k, a.ctypes.data)
@@ -209,7 +222,7 @@ class Crs:
             self.m = m
         else:
             self._h = lib().zkg_crs_upload(C.byref(pk))
-            self.m = 1 << pk.log_m
+            self.m = pk.domain_size or (1 << pk.log_m)
         if not self._h:
             raise ZkgError("zkg_crs_upload failed: " + lib().zkg_last_error().decode())
 

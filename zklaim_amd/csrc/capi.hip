@@ -203,6 +203,43 @@ int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset) {
     return rc;
 }
 
+int zkg_evaluation_domain_size(size_t min_size, size_t *m, int *is_step) {
+    DomainShape sh;
+    if (!evaluation_domain_shape(min_size, sh)) { set_error("zkg_evaluation_domain_size: no radix-2 or step domain for that size"); return ZKG_ERROR; }
+    if (m) *m = sh.m;
+    if (is_step) *is_step = sh.step ? 1 : 0;
+    return ZKG_OK;
+}
+int zkg_ntt_domain_dev(void *d_a, size_t m, int inverse, int coset, void *stream) {
+    REQUIRE_INIT();
+    DomainShape sh;
+    if (!domain_shape_of(m, sh)) { set_error("zkg_ntt_domain: m is neither 2^k nor 2^a + 2^b (get_evaluation_domain would not return it)"); return ZKG_ERROR; }
+    if (!sh.step) return zkg_ntt_dev(d_a, sh.log_m, inverse, coset, stream);
+    hipStream_t s = (hipStream_t)stream;
+    StepDomain *d = step_domain(m, s);
+    if (!d) return ZKG_ERROR;
+    DevBuf scratch;                                           // one-off call: the prover keeps its own
+    if (scratch.reserve(m * 32)) return ZKG_ERROR;
+    int rc = step_ntt_run(d, (Fr *)d_a, inverse != 0, coset != 0, s, scratch.as<Fr>());
+    if (!hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__)) rc = ZKG_ERROR;
+    scratch.release();
+    return rc;
+}
+int zkg_ntt_domain(uint64_t *a, size_t m, int inverse, int coset) {
+    REQUIRE_INIT();
+    if (!a || m < 2) { set_error("zkg_ntt_domain: bad argument"); return ZKG_ERROR; }
+    size_t bytes = m * 32;
+    DevBuf buf;
+    if (buf.reserve(bytes)) return ZKG_ERROR;
+    int rc = ZKG_ERROR;
+    if (hip_ok(hipMemcpy(buf.p, a, bytes, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+        zkg_ntt_domain_dev(buf.p, m, inverse, coset, nullptr) == ZKG_OK &&
+        hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) &&
+        hip_ok(hipMemcpy(a, buf.p, bytes, hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) rc = ZKG_OK;
+    buf.release();
+    return rc;
+}
+
 int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
     REQUIRE_INIT();
     G1 r;

@@ -177,14 +177,14 @@ extern "C" zkg_crs *zkg_crs_upload_blob(const void *blob, size_t len) {
         }
     d_rec.release(); d_out.release(); d_flag.release();
     size_t m_dom = nH + 1;
-    unsigned log_m = 0; while (((size_t)1 << log_m) < m_dom) ++log_m;
-    if (((size_t)1 << log_m) != m_dom) { set_error("pk blob: H_query length + 1 is not a power of two (only basic_radix2 domains are supported)"); return nullptr; }
+    DomainShape shape;                                     // the domain size is not stored in the blob: H_query has m - 1 entries
+    if (!domain_shape_of(m_dom, shape)) { set_error("pk blob: H_query length + 1 is neither a power of two nor a step_radix2 size 2^a + 2^b"); return nullptr; }
     zkg_pk pk; memset(&pk, 0, sizeof(pk));
     pk.cs.num_variables = (uint32_t)(nA - 1); pk.cs.num_inputs = (uint32_t)primary; pk.cs.num_constraints = (uint32_t)ncons;
     pk.cs.a_rowptr = rp[0].data(); pk.cs.a_col = col[0].data(); pk.cs.a_val = val[0].data();
     pk.cs.b_rowptr = rp[1].data(); pk.cs.b_col = col[1].data(); pk.cs.b_val = val[1].data();
     pk.cs.c_rowptr = rp[2].data(); pk.cs.c_col = col[2].data(); pk.cs.c_val = val[2].data();
-    pk.log_m = log_m;
+    pk.log_m = shape.log_m; pk.domain_size = (uint32_t)shape.m;
     pk.alpha_g1 = small1.data(); pk.beta_g1 = small1.data() + 8; pk.delta_g1 = small1.data() + 16;
     pk.beta_g2 = small2.data(); pk.delta_g2 = small2.data() + 16;
     pk.A_query = A_query.data(); pk.B_g1 = B_g1.data(); pk.B_g2 = B_g2.data(); pk.H_query = H_query.data(); pk.L_query = L_query.data();

@@ -55,8 +55,36 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s);     // cached per size
 // mode: inverse / coset as in zkg_ntt.  extra_post (device, N Fr, optional) replaces the default
 // post table: the prover fuses iFFT's 1/N with the following cosetFFT's g^i through it.
 int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s);
-// batch > 1: `batch` vectors of N elements back to back in d_a (and in `scratch`, which must then be given), one launch per pass
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr, unsigned batch = 1);
+// batch > 1: `batch` vectors, batch_stride elements apart (0 = N: back to back) in d_a and in `scratch` (which must then be given),
+// one launch per pass
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr,
+               unsigned batch = 1, size_t batch_stride = 0);
+
+// libfqfft get_evaluation_domain(min_size) for min_size <= 2^28: basic_radix2_domain (m = 2^k) or step_radix2_domain (m = big + small,
+// big = 2^(ceil_log2(m)-1), small = 2^b < big).  zklaim's circuits land on a step domain for 10 of the 20 payload counts.
+struct DomainShape { size_t m = 0, big = 0, small = 0; bool step = false; unsigned log_m = 0; /* ceil(log2 m) */ };
+bool evaluation_domain_shape(size_t min_size, DomainShape &d);
+bool domain_shape_of(size_t m, DomainShape &d);           // m must be a size the rule maps to itself
+Fr fr_root_of_unity_pow2(unsigned logn);                  // libff::get_root_of_unity(2^logn)
+// evaluate_all_lagrange_polynomials(t) and compute_vanishing_polynomial(t) of the domain (host, one batched inversion)
+int domain_lagrange(const DomainShape &d, const Fr &t, std::vector<Fr> &u, Fr &Zt);
+
+// step_radix2_domain on the device: FFT = fold (mod x^big - 1 | x -> omega x, mod x^small - 1) + one radix-2 transform of each size
+struct StepDomain {
+    DomainShape shape;
+    NttDomain *dbig = nullptr, *dsmall = nullptr;
+    DevBuf w;                     // omega^i, i < big          (omega = root of unity of order 2 big)
+    DevBuf winv_half;             // omega^-i / 2, i < small
+    DevBuf g_pow, ginv_pow;       // g^i, g^-i, i < m          (coset variants)
+    DevBuf zinv;                  // 1 / Z(g x_i) for i < big: period big/small entries (divide_by_Z_on_coset)
+    Fr zinv_small;                // 1 / Z(g x_i), i >= big
+    Fr big_inv, small_inv, half;
+    int init(const DomainShape &sh, hipStream_t s);
+    void release();
+};
+StepDomain *step_domain(size_t m, hipStream_t s);         // cached per size
+// a: batch vectors of m elements, batch_stride apart; scratch: same shape
+int step_ntt_run(StepDomain *d, Fr *d_a, bool inverse, bool coset, hipStream_t s, Fr *scratch, unsigned batch = 1, size_t batch_stride = 0);
 int powers_table(Fr *d_out, size_t n, const Fr &base, const Fr &scale, hipStream_t s);   // out[i] = scale * base^i
 void ntt_release_all();
 int ntt_configure();

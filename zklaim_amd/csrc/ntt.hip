@@ -107,11 +107,16 @@ static Fr fr_root_of_unity() {
     return r;
 }
 
+Fr fr_root_of_unity_pow2(unsigned logn) {                               // libff::get_root_of_unity(2^logn)
+    Fr omega = fr_root_of_unity();
+    for (unsigned i = 28; i > logn; --i) omega = omega.sqr();
+    return omega;
+}
+
 int NttDomain::init(unsigned logn_, hipStream_t s) {
     logn = logn_;
     size_t N = (size_t)1 << logn;
-    Fr omega = fr_root_of_unity();
-    for (unsigned i = 28; i > logn; --i) omega = omega.sqr();          // libff::get_root_of_unity
+    Fr omega = fr_root_of_unity_pow2(logn);
     Fr g = Fr::from_u64(5);                                            // Fr::multiplicative_generator
     n_inv = Fr::from_u64(N).inverse();
     size_t half = N > 1 ? N / 2 : 1;
@@ -140,6 +145,7 @@ Fr *NttDomain::scratch_for(hipStream_t s) {
 
 static std::mutex g_dom_mu;
 static std::map<unsigned, NttDomain *> g_domains;
+static std::map<size_t, StepDomain *> g_step_domains;
 NttDomain *ntt_domain(unsigned logn, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_dom_mu);
     auto it = g_domains.find(logn);
@@ -156,11 +162,14 @@ void ntt_release_all() {
     std::lock_guard<std::mutex> lk(g_dom_mu);
     for (auto &kv : g_domains) { kv.second->release(); delete kv.second; }
     g_domains.clear();
+    for (auto &kv : g_step_domains) { kv.second->release(); delete kv.second; }
+    g_step_domains.clear();
 }
 
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch, unsigned batch) {
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch, unsigned batch, size_t batch_stride) {
     const unsigned n = d->logn;
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
+    if (batch > 1 && !scratch) { set_error("ntt: a batched transform needs its own scratch"); return ZKG_ERROR; }
     const size_t N = (size_t)1 << n;
     unsigned npass = (n + NTT_MAX_R - 1) / NTT_MAX_R;
     if (n <= (unsigned)NTT_TILE_LOG) npass = 1;
@@ -180,7 +189,7 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
         A.has_post_scalar = (p == npass - 1 && post_scalar && !post) ? 1 : 0;
         A.post_scalar = A.has_post_scalar ? *post_scalar : Fr::zero();
         A.n_log = n; A.s0 = s0; A.R = R;
-        A.src_batch_stride = N; A.dst_batch_stride = N;     // batched vectors (and their scratch) are laid out back to back
+        A.src_batch_stride = A.dst_batch_stride = batch_stride ? batch_stride : N;     // vectors and their scratch share one layout
         unsigned cols_log = n - R;                                   // columns in total
         A.cw_log = cols_log < (unsigned)(NTT_TILE_LOG - R) ? cols_log : (unsigned)(NTT_TILE_LOG - R);
         if (npass == 1) A.cw_log = 0;
@@ -198,6 +207,172 @@ int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s) {
     if (!inverse) return ntt_run_ex(d, d_a, false, coset ? d->coset_pre.as<Fr>() : nullptr, nullptr, nullptr, s);
     if (coset) return ntt_run_ex(d, d_a, true, nullptr, d->icoset_post.as<Fr>(), nullptr, s);
     return ntt_run_ex(d, d_a, true, nullptr, nullptr, &d->n_inv, s);
+}
+
+
+// ======================================================================================================
+// step_radix2_domain (libfqfft step_radix2_domain<Fr>): m = big + small.  The domain is the big-th roots of unity
+// followed by the coset omega * (small-th roots of unity), omega of order 2 big.  Both transforms are one pass of
+// elementwise work around a radix-2 transform of size big and one of size small; lane i owns every index congruent
+// to i mod small, so the fold / unfold kernels work in place without atomics.
+// ======================================================================================================
+static unsigned ceil_log2(size_t x) { unsigned r = 0; while (((size_t)1 << r) < x) ++r; return r; }
+
+bool evaluation_domain_shape(size_t min_size, DomainShape &d) {
+    if (min_size <= 1) return false;
+    unsigned lg = ceil_log2(min_size);
+    if (lg > 28) return false;
+    d = DomainShape();
+    d.log_m = lg;
+    if (min_size == ((size_t)1 << lg)) { d.m = min_size; return true; }                    // basic_radix2_domain(min_size)
+    size_t big = (size_t)1 << (lg - 1), small = min_size - big, rounded_small = (size_t)1 << ceil_log2(small);
+    if (small != rounded_small && big == rounded_small) { d.m = big + rounded_small; return true; }   // basic_radix2_domain(big + rounded_small)
+    d.step = true; d.big = big; d.small = rounded_small; d.m = big + rounded_small;         // step_radix2_domain(min_size | big + rounded_small)
+    return true;
+}
+bool domain_shape_of(size_t m, DomainShape &d) { return evaluation_domain_shape(m, d) && d.m == m; }
+
+// evaluate_all_lagrange_polynomials(t), compute_vanishing_polynomial(t).  Closed forms with ONE batched inversion:
+//   basic:  u_i = Z(t) w^i / (m (t - w^i)),                                   Z(t) = t^m - 1
+//   step:   u_i = Zb(t) wb^i (t^small - omega^small) / (big (t - wb^i)(wb^(i small) - omega^small))   for i < big
+//           u_(big+i) = (t^big - 1)/(omega^big - 1) * Zs(t') ws^i / (small (t' - ws^i)),  t' = t / omega
+static int batch_invert(std::vector<Fr> &den) {
+    std::vector<Fr> pre(den.size());
+    Fr run = Fr::one();
+    for (size_t i = 0; i < den.size(); ++i) { if (den[i].is_zero()) return ZKG_ERROR; pre[i] = run; run = run * den[i]; }
+    Fr inv = run.inverse();
+    for (size_t i = den.size(); i-- > 0;) { Fr di = inv * pre[i]; inv = inv * den[i]; den[i] = di; }
+    return ZKG_OK;
+}
+int domain_lagrange(const DomainShape &d, const Fr &t, std::vector<Fr> &u, Fr &Zt) {
+    const size_t m = d.m;
+    u.assign(m, Fr::zero());
+    std::vector<Fr> den(m);
+    if (!d.step) {
+        Fr omega = fr_root_of_unity_pow2(d.log_m), wi = Fr::one(), mf = Fr::from_u64(m);
+        Zt = t.pow_u64(m) - Fr::one();
+        for (size_t i = 0; i < m; ++i) { u[i] = Zt * wi; den[i] = mf * (t - wi); wi = wi * omega; }
+    } else {
+        const size_t big = d.big, small = d.small;
+        Fr omega = fr_root_of_unity_pow2(d.log_m), wb = omega.sqr(), ws = fr_root_of_unity_pow2(ceil_log2(small));
+        Fr omega_s = omega.pow_u64(small), Zb = t.pow_u64(big) - Fr::one(), L0 = t.pow_u64(small) - omega_s;
+        Zt = Zb * L0;
+        Fr wbs = wb.pow_u64(small), wi = Fr::one(), elt = Fr::one(), bf = Fr::from_u64(big), num = Zb * L0;
+        for (size_t i = 0; i < big; ++i) { u[i] = num * wi; den[i] = bf * (t - wi) * (elt - omega_s); wi = wi * wb; elt = elt * wbs; }
+        Fr tp = t * omega.inverse(), Zs = tp.pow_u64(small) - Fr::one(), sf = Fr::from_u64(small);
+        Fr L1num = Zb * Zs, L1den = omega.pow_u64(big) - Fr::one();
+        wi = Fr::one();
+        for (size_t i = 0; i < small; ++i) { u[big + i] = L1num * wi; den[big + i] = L1den * sf * (tp - wi); wi = wi * ws; }
+    }
+    if (batch_invert(den)) { set_error("domain_lagrange: t is a domain point"); return ZKG_ERROR; }
+    for (size_t i = 0; i < m; ++i) u[i] = u[i] * den[i];
+    return ZKG_OK;
+}
+
+struct StepArgs {
+    Fr *a; const Fr *w, *winv_half, *g;      // g: g^i (fold, coset) or g^-i (unfold, icoset); null for the plain transforms
+    size_t big, small, stride; uint32_t compr;
+    Fr half;
+};
+// coefficients -> (c | e): c = p mod (x^big - 1) in a[0, big), e = p(omega x) mod (x^small - 1) in a[big, m)
+__global__ __launch_bounds__(256) void k_step_fold(StepArgs A) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.small) return;
+    Fr *a = A.a + (size_t)blockIdx.y * A.stride;
+    Fr hi = a[A.big + i];
+    if (A.g) hi = hi * A.g[A.big + i];
+    Fr e = Fr::zero();
+    for (uint32_t j = 0; j < A.compr; ++j) {
+        size_t k = i + (size_t)j * A.small;
+        Fr x = a[k];
+        if (A.g) x = x * A.g[k];
+        Fr c = x, d = x;
+        if (j == 0) { c = x + hi; d = x - hi; }
+        a[k] = c.normalized();
+        e += A.w[k] * d;
+    }
+    a[A.big + i] = e.normalized();
+}
+// (U0 | U1) = (p mod (x^big - 1) | p(omega x) mod (x^small - 1)) -> the m coefficients of p
+__global__ __launch_bounds__(256) void k_step_unfold(StepArgs A) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.small) return;
+    Fr *a = A.a + (size_t)blockIdx.y * A.stride;
+    Fr u1 = a[A.big + i];
+    for (uint32_t j = 1; j < A.compr; ++j) {                 // the suffix coefficients are U0's own; remove their image from U1
+        size_t k = i + (size_t)j * A.small;
+        Fr x = a[k];
+        u1 -= x * A.w[k];
+        if (A.g) a[k] = (x * A.g[k]).normalized();
+    }
+    Fr u1h = u1 * A.winv_half[i], u0h = a[i] * A.half;
+    Fr lo = u0h + u1h, hi = u0h - u1h;
+    if (A.g) { lo = lo * A.g[i]; hi = hi * A.g[A.big + i]; }
+    a[i] = lo.normalized(); a[A.big + i] = hi.normalized();
+}
+
+int StepDomain::init(const DomainShape &sh, hipStream_t s) {
+    shape = sh;
+    const size_t big = sh.big, small = sh.small, m = sh.m;
+    dbig = ntt_domain(ceil_log2(big), s); dsmall = ntt_domain(ceil_log2(small), s);
+    if (!dbig || !dsmall) return ZKG_ERROR;
+    Fr omega = fr_root_of_unity_pow2(sh.log_m), g = Fr::from_u64(5);
+    half = Fr::from_u64(2).inverse(); big_inv = Fr::from_u64(big).inverse(); small_inv = Fr::from_u64(small).inverse();
+    const size_t compr = big / small;
+    if (w.reserve(big * sizeof(Fr)) || winv_half.reserve(small * sizeof(Fr)) || g_pow.reserve(m * sizeof(Fr)) || ginv_pow.reserve(m * sizeof(Fr)) ||
+        zinv.reserve(compr * sizeof(Fr))) return ZKG_ERROR;
+    if (powers_table(w.as<Fr>(), big, omega, Fr::one(), s) || powers_table(winv_half.as<Fr>(), small, omega.inverse(), half, s) ||
+        powers_table(g_pow.as<Fr>(), m, g, Fr::one(), s) || powers_table(ginv_pow.as<Fr>(), m, g.inverse(), Fr::one(), s)) return ZKG_ERROR;
+    // divide_by_Z_on_coset: Z(x) = (x^big - 1)(x^small - omega^small) at x = g wb^i (i < big) and x = g omega ws^i
+    Fr Z0 = g.pow_u64(big) - Fr::one(), gs = g.pow_u64(small), os = omega.pow_u64(small), step = omega.pow_u64(2 * small), elt = Fr::one();
+    std::vector<Fr> den(compr);
+    for (size_t i = 0; i < compr; ++i) { den[i] = Z0 * (gs * elt - os); elt = elt * step; }
+    Fr go = g * omega, z1 = (go.pow_u64(big) - Fr::one()) * (go.pow_u64(small) - os);
+    if (batch_invert(den) || z1.is_zero()) { set_error("step domain: Z vanishes on the coset"); return ZKG_ERROR; }
+    zinv_small = z1.inverse();
+    if (!hip_ok(hipMemcpyAsync(zinv.p, den.data(), compr * sizeof(Fr), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__) ||
+        !hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__)) return ZKG_ERROR;
+    return ZKG_OK;
+}
+void StepDomain::release() { w.release(); winv_half.release(); g_pow.release(); ginv_pow.release(); zinv.release(); }
+
+StepDomain *step_domain(size_t m, hipStream_t s) {
+    DomainShape sh;
+    if (!domain_shape_of(m, sh) || !sh.step) { set_error("step_domain: not a step_radix2 size"); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_dom_mu);
+        auto it = g_step_domains.find(m);
+        if (it != g_step_domains.end()) return it->second;
+    }
+    StepDomain *d = new StepDomain();                         // built outside the lock: init takes it through ntt_domain()
+    if (d->init(sh, s) != ZKG_OK) { d->release(); delete d; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_dom_mu);
+    auto it = g_step_domains.find(m);
+    if (it != g_step_domains.end()) { d->release(); delete d; return it->second; }
+    g_step_domains[m] = d;
+    return d;
+}
+
+int step_ntt_run(StepDomain *d, Fr *a, bool inverse, bool coset, hipStream_t s, Fr *scratch, unsigned batch, size_t batch_stride) {
+    const size_t big = d->shape.big, small = d->shape.small, stride = batch_stride ? batch_stride : d->shape.m;
+    if (!scratch) { set_error("step ntt: scratch required"); return ZKG_ERROR; }
+    StepArgs A;
+    A.a = a; A.w = d->w.as<Fr>(); A.winv_half = d->winv_half.as<Fr>(); A.big = big; A.small = small; A.stride = stride;
+    A.compr = (uint32_t)(big / small); A.half = d->half;
+    dim3 grid((unsigned)((small + 255) / 256), batch);
+    if (!inverse) {
+        A.g = coset ? d->g_pow.as<Fr>() : nullptr;
+        hipLaunchKernelGGL(k_step_fold, grid, dim3(256), 0, s, A);
+        if (ntt_run_ex(d->dbig, a, false, nullptr, nullptr, nullptr, s, scratch, batch, stride)) return ZKG_ERROR;
+        if (ntt_run_ex(d->dsmall, a + big, false, nullptr, nullptr, nullptr, s, scratch + big, batch, stride)) return ZKG_ERROR;
+    } else {
+        if (ntt_run_ex(d->dbig, a, true, nullptr, nullptr, &d->big_inv, s, scratch, batch, stride)) return ZKG_ERROR;
+        if (ntt_run_ex(d->dsmall, a + big, true, nullptr, nullptr, &d->small_inv, s, scratch + big, batch, stride)) return ZKG_ERROR;
+        A.g = coset ? d->ginv_pow.as<Fr>() : nullptr;
+        hipLaunchKernelGGL(k_step_unfold, grid, dim3(256), 0, s, A);
+    }
+    if (hipGetLastError() != hipSuccess) { set_error("step ntt launch failed"); return ZKG_ERROR; }
+    return ZKG_OK;
 }
 
 }  // namespace zk

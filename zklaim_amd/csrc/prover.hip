@@ -30,7 +30,8 @@ struct zkg_crs {
     zk::DevCsr A, B, Cm;
     zk::DevBuf A_query, B_g1, B_g2, H_query, L_query;
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
-    zk::NttDomain *dom = nullptr;
+    zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
+    zk::StepDomain *sdom = nullptr;             // ... or step_radix2_domain (m = 2^(log_m-1) + 2^b); exactly one is set
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
     zk::DevBuf z, aABC, flag;                   // [1 | w] and the three evaluation vectors aA | aB | aC back to back (batched NTTs)
     zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
@@ -100,6 +101,14 @@ __global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, 
     if (i < C && aA[i] * aB[i] != aC[i]) atomicOr(flag, 1u);
 }
 
+// the same on a step_radix2_domain: Z(g x_i) takes big/small distinct values on the first big points and one on the rest
+__global__ __launch_bounds__(256) void k_pointwise_h_step(Fr *aA, const Fr *aB, const Fr *aC, size_t m, size_t big, const Fr *zinv, uint32_t period_mask, Fr zinv_small) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr zi = i < big ? zinv[i & period_mask] : zinv_small;
+    aA[i] = ((aA[i] * aB[i] - aC[i]) * zi).normalized();
+}
+
 __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one(); }
 
 // H_tmp = (aA . aB - aC) * Zinv  (divide_by_Z_on_coset fused with the pointwise product)
@@ -159,13 +168,25 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
         ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
     }
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
-    // iFFT then cosetFFT of aA, aB, aC as ONE batch of three (a single 2^18 transform fills half the chip; three fill it):
-    // inverse transform with the fused post table g^i/m, then a plain forward transform
-    const Fr *fused = crs->coset_over_m.as<Fr>();
-    if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, crs->ntt_scratch.as<Fr>(), 3)) return ZKG_ERROR;
-    if (ntt_run_ex(crs->dom, aA, false, nullptr, nullptr, nullptr, s, crs->ntt_scratch.as<Fr>(), 3)) return ZKG_ERROR;
-    hipLaunchKernelGGL(k_pointwise_h, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
-    if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, crs->ntt_scratch.as<Fr>())) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
+    Fr *scr = crs->ntt_scratch.as<Fr>();
+    const unsigned grid_m = (unsigned)((m + 255) / 256);
+    if (crs->dom) {
+        // iFFT then cosetFFT of aA, aB, aC as ONE batch of three (a single 2^18 transform fills half the chip; three fill it):
+        // inverse transform with the fused post table g^i/m, then a plain forward transform
+        const Fr *fused = crs->coset_over_m.as<Fr>();
+        if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, scr, 3)) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, aA, false, nullptr, nullptr, nullptr, s, scr, 3)) return ZKG_ERROR;
+        hipLaunchKernelGGL(k_pointwise_h, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
+        if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, scr)) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
+    } else {
+        // step_radix2_domain: the same four steps, each transform a fold/unfold pass around a 2^a and a 2^b radix-2 transform
+        StepDomain *sd = crs->sdom;
+        if (step_ntt_run(sd, aA, true, false, s, scr, 3, m)) return ZKG_ERROR;                     // iFFT  x3
+        if (step_ntt_run(sd, aA, false, true, s, scr, 3, m)) return ZKG_ERROR;                     // cosetFFT x3
+        hipLaunchKernelGGL(k_pointwise_h_step, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, sd->shape.big, sd->zinv.as<Fr>(),
+                           (uint32_t)(sd->shape.big / sd->shape.small - 1), sd->zinv_small);
+        if (step_ntt_run(sd, aA, true, true, s, scr, 1, m)) return ZKG_ERROR;                      // icosetFFT
+    }
     if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
     if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
@@ -182,11 +203,13 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("zkg_crs_upload: no HIP device (call zkg_init)"); return nullptr; }
     const zkg_r1cs &cs = pk->cs;
-    if (pk->log_m > 28 || ((size_t)cs.num_constraints + cs.num_inputs + 1) > ((size_t)1 << pk->log_m) || cs.num_inputs > cs.num_variables) {
-        set_error("zkg_crs_upload: inconsistent sizes"); return nullptr;
+    DomainShape shape;
+    if (pk->log_m > 28 || !domain_shape_of(pk->domain_size ? (size_t)pk->domain_size : ((size_t)1 << pk->log_m), shape) || shape.log_m != pk->log_m ||
+        ((size_t)cs.num_constraints + cs.num_inputs + 1) > shape.m || cs.num_inputs > cs.num_variables) {
+        set_error("zkg_crs_upload: inconsistent sizes (domain must be 2^log_m or a step_radix2 size 2^(log_m-1) + 2^b)"); return nullptr;
     }
     zkg_crs *crs = new zkg_crs();
-    crs->n = cs.num_variables; crs->l = cs.num_inputs; crs->C = cs.num_constraints; crs->log_m = pk->log_m; crs->m = (size_t)1 << pk->log_m;
+    crs->n = cs.num_variables; crs->l = cs.num_inputs; crs->C = cs.num_constraints; crs->log_m = pk->log_m; crs->m = shape.m;
     const size_t n = crs->n, l = crs->l, m = crs->m;
     bool ok = upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
               upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
@@ -204,14 +227,16 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     if (ok) {
         memcpy(&crs->alpha_g1, pk->alpha_g1, 64); memcpy(&crs->beta_g1, pk->beta_g1, 64); memcpy(&crs->delta_g1, pk->delta_g1, 64);
         memcpy(&crs->beta_g2, pk->beta_g2, 128); memcpy(&crs->delta_g2, pk->delta_g2, 128);
-        crs->dom = ntt_domain(pk->log_m, nullptr);
-        ok = crs->dom != nullptr;
+        if (shape.step) crs->sdom = step_domain(shape.m, nullptr); else crs->dom = ntt_domain(pk->log_m, nullptr);
+        ok = crs->dom != nullptr || crs->sdom != nullptr;
     }
-    if (ok) {
+    if (ok && crs->dom) {
         Fr g = Fr::from_u64(5);
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
-        ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
-             crs->z.reserve((n + 1) * 32) == 0 && crs->aABC.reserve(3 * m * 32) == 0 &&
+        ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0;
+    }
+    if (ok) {
+        ok = crs->z.reserve((n + 1) * 32) == 0 && crs->aABC.reserve(3 * m * 32) == 0 &&
              crs->flag.reserve(4) == 0 && crs->ntt_scratch.reserve(3 * m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
     }
     if (ok) {

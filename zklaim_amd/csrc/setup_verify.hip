@@ -23,7 +23,7 @@ using zk::pairing::Fq12;
 struct zkg_keypair {
     // the (possibly swapped) constraint system stored in the pk
     std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
-    uint32_t n = 0, l = 0, C = 0, log_m = 0; bool swapped = false;
+    uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0; bool swapped = false;
     G1Affine alpha_g1, beta_g1, delta_g1; G2Affine beta_g2, delta_g2, gamma_g2;
     std::vector<G1Affine> A_query, B_g1, H_query, L_query, IC;
     std::vector<G2Affine> B_g2;
@@ -106,24 +106,17 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
         for (size_t i = 0; i <= n; ++i) { na += ta[i]; nb += tb[i]; }
         if (nb > na) { kp->rp[0].swap(kp->rp[1]); kp->col[0].swap(kp->col[1]); kp->val[0].swap(kp->val[1]); kp->swapped = true; }
     }
-    size_t need = C + l + 1; unsigned log_m = 1; while (((size_t)1 << log_m) < need) ++log_m;
-    if (log_m > 28) { set_error("zkg_groth16_setup: system too large for the 2-adicity of Fr"); delete kp; return nullptr; }
-    kp->log_m = log_m;
-    const size_t m = (size_t)1 << log_m;
+    DomainShape shape;                                                     // libfqfft get_evaluation_domain(C + l + 1)
+    if (!evaluation_domain_shape(C + l + 1, shape)) { set_error("zkg_groth16_setup: system too large for the 2-adicity of Fr"); delete kp; return nullptr; }
+    const unsigned log_m = shape.log_m;
+    kp->log_m = log_m; kp->m = shape.m;
+    const size_t m = shape.m;
     Fr t, alpha, beta, gamma, delta;
     if (trapdoor) { t = fr_from_canonical(trapdoor); alpha = fr_from_canonical(trapdoor + 4); beta = fr_from_canonical(trapdoor + 8); gamma = fr_from_canonical(trapdoor + 12); delta = fr_from_canonical(trapdoor + 16); }
     else { t = random_fr(); alpha = random_fr(); beta = random_fr(); gamma = random_fr(); delta = random_fr(); }
-    // ---- Lagrange coefficients u_i = Z(t) w^i / (m (t - w^i)) with one batched inversion
-    Fr omega = fr_root_of_unity_2p28();
-    for (unsigned i = 28; i > log_m; --i) omega = omega.sqr();
-    Fr Zt = t.pow_u64(m) - Fr::one();
-    std::vector<Fr> u(m), den(m), pre(m);
-    {
-        Fr wi = Fr::one(), mf = Fr::from_u64(m), run = Fr::one();
-        for (size_t i = 0; i < m; ++i) { u[i] = Zt * wi; den[i] = mf * (t - wi); if (den[i].is_zero()) { set_error("zkg_groth16_setup: t is a domain point"); delete kp; return nullptr; } pre[i] = run; run = run * den[i]; wi = wi * omega; }
-        Fr inv = run.inverse();
-        for (size_t i = m; i-- > 0;) { Fr di = inv * pre[i]; inv = inv * den[i]; u[i] = u[i] * di; }
-    }
+    // ---- Lagrange coefficients u_i = L_i(t) and Z(t) on the chosen domain (closed forms, one batched inversion)
+    Fr Zt; std::vector<Fr> u;
+    if (domain_lagrange(shape, t, u, Zt)) { delete kp; return nullptr; }
     // ---- QAP polynomials at t (r1cs_to_qap_instance_map_with_evaluation)
     std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
     for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
@@ -154,7 +147,7 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     v.cs.a_rowptr = kp->rp[0].data(); v.cs.a_col = kp->col[0].data(); v.cs.a_val = kp->val[0].data();
     v.cs.b_rowptr = kp->rp[1].data(); v.cs.b_col = kp->col[1].data(); v.cs.b_val = kp->val[1].data();
     v.cs.c_rowptr = kp->rp[2].data(); v.cs.c_col = kp->col[2].data(); v.cs.c_val = kp->val[2].data();
-    v.log_m = log_m;
+    v.log_m = log_m; v.domain_size = (uint32_t)m;
     v.alpha_g1 = (const uint64_t *)&kp->alpha_g1; v.beta_g1 = (const uint64_t *)&kp->beta_g1; v.delta_g1 = (const uint64_t *)&kp->delta_g1;
     v.beta_g2 = (const uint64_t *)&kp->beta_g2; v.delta_g2 = (const uint64_t *)&kp->delta_g2;
     v.A_query = (const uint64_t *)kp->A_query.data(); v.B_g1 = (const uint64_t *)kp->B_g1.data(); v.B_g2 = (const uint64_t *)kp->B_g2.data();
