@@ -80,7 +80,7 @@ def extras(zkg, torch, args, with_cpu):
     #      k payloads -> m = 2^logm (k = 8 -> 2^18, BASELINE configs[3]; k = 20 -> 2^20, the north-star size).  Keys come from the
     #      product's GPU generator with a fixed trapdoor; (r, s) fixed; the CPU oracle proves the same instance for byte parity.
     logm = args.prove_logm
-    k_payloads = {15: 1, 16: 2, 18: 8, 20: 20}.get(logm, 8)
+    k_payloads = {15: 1, 16: 2, 17: 4, 18: 8, 19: 16, 20: 38}.get(logm, 8)      # 38 payloads: C + l + 1 = 1 047 968 -> m = 2^20
     t_syn = time.perf_counter()
     keep = []
     pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i)
@@ -108,7 +108,7 @@ def extras(zkg, torch, args, with_cpu):
     A, B, C = ck.csr()
     nnz = int(len(A[1]) + len(B[1]) + len(C[1]))
     alg_bytes = 7 * 64 * m + 96 * (nv + 1) + (128 + 64 + 32) * (nv + 1) + 96 * (m - 1) + 96 * (nv - l)
-    g = {"circuit": f"zklaim_gadget, {k_payloads} payloads (SHA-256 + 5 comparisons each)", "log_m": logm, "num_variables": int(nv), "num_inputs": int(l),
+    g = {"circuit": f"zklaim_gadget, {k_payloads} payloads (SHA-256 + 5 comparisons each)", "log_m": logm, "domain_size": int(m), "num_variables": int(nv), "num_inputs": int(l),
          "num_constraints": int(ncons), "nnz": nnz, "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3),
          "algorithmic_bytes_per_proof": int(alg_bytes), "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
          "stage_names": ["r1cs_matvec", "7_ntt+pointwise", "msm_A", "msm_B_g1", "msm_B_g2", "msm_H", "msm_L", "wall_total_incl_host_assembly"],
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--logn", type=int, default=LOGN, help="log2 points per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
-    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 20 payloads")
+    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 38 payloads (the north star's 2^20-constraint case)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print banners (RCCL prints its version on first use) go to stderr
