@@ -93,6 +93,7 @@ int ntt_configure();
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
 MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);
 hipStream_t msm_job_stream(MsmJob *j);
+void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_destroy(MsmJob *j);
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);

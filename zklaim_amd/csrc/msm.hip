@@ -55,9 +55,18 @@ struct MsmGeom { uint32_t c, W, B; };        // window bits, windows, buckets pe
 struct HeavyItem { uint32_t start, end; };   // a part: range of the sorted index list
 struct HeavyBucket { uint32_t gb, first_item, nparts; };
 
-static MsmGeom pick_geom(size_t n) {
+// Window size.  Measured on MI355X with uniformly random scalars (tools/msm_c_sweep.py): the accumulation runs one lane per
+// bucket, so it needs W * 2^(c-1) >> 64 K buckets to fill the chip, and that outweighs the extra bucket-reduction work down to
+// 2^15 points: c = 16 there, 12 below, and small windows only for tiny inputs.  `window_hint` (the prover's witness
+// multi-exponentiations, whose scalars are mostly 0/1 so that the bucket reduction dominates) overrides the rule.
+static MsmGeom pick_geom(size_t n, int window_hint) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg - 4; if (c < 4) c = 4; if (c > MAX_C) c = MAX_C;
+    int c = lg >= 15 ? 16 : lg >= 11 ? 12 : lg + 1;
+    if (c < 4) c = 4;
+    if (window_hint > 0) c = window_hint;
+    static const char *force = getenv("ZKG_MSM_C");                          // tuning aid
+    if (force && atoi(force) >= 2) c = atoi(force);
+    if (c > MAX_C) c = MAX_C;
     MsmGeom g; g.c = c; g.W = (SCALAR_BITS + c - 1) / c; g.B = 1u << (c - 1);
     return g;
 }
@@ -377,6 +386,7 @@ struct MsmJob {
     DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted;
     MsmSlot slot[3]; int nslots = 0;
     MsmGeom g{}; size_t n = 0; uint32_t cpw = 0; size_t nred = 0; int red_l_log = RED_L_LOG_SMALL;
+    int window_hint = 0;               // 0: pick_geom's rule
     std::mutex mu;
 };
 
@@ -479,6 +489,7 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     }
     return j;
 }
+void msm_job_set_window(MsmJob *j, int c) { if (j) j->window_hint = c; }
 hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
 void msm_job_destroy(MsmJob *j) {
     if (!j) return;
@@ -496,7 +507,7 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
-    job->g = pick_geom(n); job->n = n;
+    job->g = pick_geom(n, job->window_hint); job->n = n;
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
     job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
     { uint32_t chunk = RED_LANES << job->red_l_log; job->cpw = (job->g.B + chunk - 1) / chunk; }

@@ -246,6 +246,14 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         crs->job_a = msm_job_create(nullptr, true); crs->job_b1 = msm_job_create(nullptr, true); crs->job_b2 = msm_job_create(nullptr, true);
         crs->job_h = msm_job_create(nullptr, true, true); crs->job_l = msm_job_create(nullptr, true);
         ok = ok && crs->job_a && crs->job_b1 && crs->job_b2 && crs->job_h && crs->job_l;
+        if (ok) {
+            // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
+            // mostly 0/1 scalars (one heavy bucket) and few full-size ones, so their time is the bucket reduction's: small windows.
+            const char *cw = getenv("ZKG_MSM_C_W"), *c2 = getenv("ZKG_MSM_C_G2");           // tuning aids
+            int w1 = cw ? atoi(cw) : 12, w2 = c2 ? atoi(c2) : w1;
+            for (MsmJob *j : {crs->job_a, crs->job_b1, crs->job_l}) msm_job_set_window(j, w1);
+            msm_job_set_window(crs->job_b2, w2);
+        }
     }
     if (ok) {
         crs->ev_ok = true;
@@ -288,7 +296,7 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     hipStream_t s = crs->stream;
     const size_t n = crs->n, l = crs->l, m = crs->m;
     auto t_wall0 = std::chrono::steady_clock::now();
-    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr, serial = getenv("ZKG_SERIAL_MSM") != nullptr;
     auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count()); };
     uint32_t flag = 0;
     if (compute_h(crs, witness, check_satisfied != 0, &flag, s)) return ZKG_ERROR;
@@ -310,6 +318,7 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
         (void)hipEventRecord(crs->ev[L.ev0], js);
         if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
         (void)hipEventRecord(crs->ev[L.ev0 + 1], js);
+        if (serial) (void)hipStreamSynchronize(js);                         // profiling aid: one multi-exponentiation at a time
         lap("  job enqueued");
     }
     lap("msm jobs enqueued");
@@ -329,16 +338,21 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
             set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
         }
     }
-    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr) ||
-        msm_job_finish(crs->job_h, &Ht, nullptr)) return ZKG_ERROR;
+    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr)) return ZKG_ERROR;
+    // H and B_g2 end last, in either order: the host tail of whichever is ready first runs while the other is still on the GPU
+    bool g2_done = false;
+    if (hipStreamQuery(msm_job_stream(crs->job_b2)) == hipSuccess) { if (msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR; g2_done = true; }
+    if (msm_job_finish(crs->job_h, &Ht, nullptr)) return ZKG_ERROR;
     lap("4 G1 msm finished");
-    if (msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR;
-    lap("G2 msm finished");
-    // ---- assembly (host).  The three products that involve only the CRS were computed while the GPU was busy (above).
+    // ---- assembly (host).  The three products that involve only the CRS were computed while the GPU was busy (above);
+    //      everything in G1 is assembled before waiting for the G2 multi-exponentiation, whose tail it overlaps.
     G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
     G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
-    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
     G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
+    lap("G1 side assembled");
+    if (!g2_done && msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR;
+    lap("G2 msm finished");
+    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
     size_t off = 0;
     off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
     *proof_len = off;
