@@ -37,8 +37,10 @@
 namespace zk {
 
 static constexpr int SCALAR_BITS = 255;      // r < 2^254; one extra bit absorbs the signed-digit carry
-static constexpr int RED_LANES = 128;         // logical lanes per reduce workgroup, four physical lanes (one DPP quad) each
-static constexpr int RED_THREADS = 4 * RED_LANES;
+// logical lanes per reduce workgroup, four physical lanes (one DPP quad) each.  G1: 128 (512 threads, 128-VGPR budget is enough for
+// three 32-register points).  G2: 64 -> 256 threads, so that the compiler may use 256 VGPRs: the kernel holds three 64-register
+// points and was spilling 1.4 KB per lane under the 128-register cap of a 512-thread workgroup.
+template <class F> struct RedGeom { static constexpr int LANES_LOG = sizeof(F) == sizeof(Fq) ? 7 : 6, LANES = 1 << LANES_LOG, THREADS = 4 * LANES; };
 // buckets per logical lane in the running-sum step, 2^L_LOG: the kernel is a dependency chain of 2(L-1) + 2 log2(128) + 2
 // additions but does (2(L-1) + 14)/L additions per bucket, so small bucket sets (latency-bound: the prover's witness MSMs)
 // take L = 4 and large ones (work-bound: 2^19 buckets at N = 2^20) take L = 16.
@@ -316,12 +318,12 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
 }
 
 // ---- 7. bucket reduction: per chunk of RED_CHUNK buckets emit P = sum X_i and U = sum i*X_i (i 0-based in chunk).
-//      RED_LANES logical lanes per workgroup, each played by the four lanes of a DPP quad (xyzz_add_quad): the kernel is a
-//      dependency chain of 2(L-1) + 2 log2(RED_LANES) + 2 additions, and the quad turns each addition's 14 dependent
+//      RedGeom<F>::LANES logical lanes per workgroup, each played by the four lanes of a DPP quad (xyzz_add_quad): the kernel is a
+//      dependency chain of 2(L-1) + 2 log2(LANES) + 2 additions, and the quad turns each addition's 14 dependent
 //      multiplications into 4 rounds.
 template <class F, int RED_L_LOG>
-__global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out) {
-    constexpr int RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
+__global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out) {
+    constexpr int RED_LANES = RedGeom<F>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);              // 2 * RED_LANES points
     const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;          // logical lane, position in its quad
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bucket_reduce(const XYZZ<F> *bu
 struct MsmSlot {                    // per base set: accumulators and the host landing zone of its chunk results
     DevBuf buckets, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
     void *host_red = nullptr; size_t host_cap = 0; bool g2 = false;
+    uint32_t cpw = 0; size_t nred = 0; int chunk_log = 0;      // reduce geometry: chunks per window, chunk results, log2(buckets per chunk)
     int host_reserve(size_t bytes) {
         if (bytes <= host_cap) return 0;
         if (host_red) (void)hipHostFree(host_red);
@@ -385,7 +388,7 @@ struct MsmJob {
     hipStream_t stream = nullptr; bool own_stream = false;
     DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted;
     MsmSlot slot[3]; int nslots = 0;
-    MsmGeom g{}; size_t n = 0; uint32_t cpw = 0; size_t nred = 0; int red_l_log = RED_L_LOG_SMALL;
+    MsmGeom g{}; size_t n = 0; int red_l_log = RED_L_LOG_SMALL;
     int window_hint = 0;               // 0: pick_geom's rule
     std::mutex mu;
 };
@@ -399,8 +402,11 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
     if (sl.heavy_items.reserve(max_items * sizeof(HeavyItem)) || sl.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
         sl.heavy_counters.reserve(8) || sl.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
     ZK_HIP(hipMemsetAsync(sl.heavy_counters.p, 0, 8, s));
-    if (sl.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || sl.red_out.reserve(job->nred * 2 * sizeof(XYZZ<F>)) ||
-        sl.host_reserve(job->nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    typedef RedGeom<F> RG;
+    sl.chunk_log = RG::LANES_LOG + job->red_l_log;
+    sl.cpw = (g.B + (1u << sl.chunk_log) - 1) >> sl.chunk_log; sl.nred = (size_t)g.W * sl.cpw;
+    if (sl.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || sl.red_out.reserve(sl.nred * 2 * sizeof(XYZZ<F>)) ||
+        sl.host_reserve(sl.nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
     XYZZ<F> *buckets = sl.buckets.as<XYZZ<F>>();
     if (time_it) g_dominant_timer.begin(s);
     hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
@@ -412,13 +418,13 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
                        sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>(), buckets);
     if (job->red_l_log == RED_L_LOG_LARGE)
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_LANES * sizeof(XYZZ<F>), s,
-                           buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+                           buckets, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
     else
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)job->nred), dim3(RED_THREADS), 2 * RED_LANES * sizeof(XYZZ<F>), s,
-                           buckets, g.B, job->cpw, sl.red_out.as<XYZZ<F>>());
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+                           buckets, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
-    ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, job->nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+    ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, sl.nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
     return ZKG_OK;
 }
 
@@ -426,7 +432,7 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
 // and P_ch to P_w; then Horner over windows (c doublings each).
 template <class F>
 static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
-    const MsmGeom g = job->g; const uint32_t cpw = job->cpw;
+    const MsmGeom g = job->g; const uint32_t cpw = sl.cpw;
     const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(sl.host_red);
     std::vector<XYZZ<F>> V(g.W);
     host_parallel_for((int)g.W, [&](int w) {                                    // the windows are independent
@@ -437,7 +443,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
-        if (!weighted.is_inf()) for (int i = 0; i < 7 + job->red_l_log; ++i) weighted = weighted.dbl();   // * chunk size (128 * L)
+        if (!weighted.is_inf()) for (int i = 0; i < sl.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
     });
@@ -448,7 +454,6 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
     }
     return acc;
 }
-static_assert(RED_LANES == 128, "chunk geometry: 128 logical lanes");
 
 static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     const MsmGeom g = job->g; const size_t n = job->n;
@@ -510,8 +515,6 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     job->g = pick_geom(n, job->window_hint); job->n = n;
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
     job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
-    { uint32_t chunk = RED_LANES << job->red_l_log; job->cpw = (job->g.B + chunk - 1) / chunk; }
-    job->nred = (size_t)job->g.W * job->cpw;
     if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
     lap("sort enqueued");
     job->nslots = 0;
@@ -585,8 +588,8 @@ int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1A
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s) { return fixed_base<Fq2>(base, d_scalars, n, d_out, s); }
 
 int msm_configure() {
-    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_LANES * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RED_LANES * (int)sizeof(G2)) == hipSuccess;
+    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;

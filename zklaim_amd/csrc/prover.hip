@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -339,10 +340,11 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
         }
     }
     if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr)) return ZKG_ERROR;
-    // H and B_g2 end last, in either order: the host tail of whichever is ready first runs while the other is still on the GPU
-    bool g2_done = false;
-    if (hipStreamQuery(msm_job_stream(crs->job_b2)) == hipSuccess) { if (msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR; g2_done = true; }
-    if (msm_job_finish(crs->job_h, &Ht, nullptr)) return ZKG_ERROR;
+    // H and B_g2 end last, in either order: B_g2's host tail (chunk sums, 255 G2 doublings: ~0.3 ms) runs on a helper thread
+    // while this one finishes H and assembles everything that lives in G1
+    auto g2_tail = std::async(std::launch::async, [&] { return msm_job_finish(crs->job_b2, nullptr, &Bt2); });
+    int rc_h = msm_job_finish(crs->job_h, &Ht, nullptr);
+    if (rc_h) { (void)g2_tail.get(); return ZKG_ERROR; }
     lap("4 G1 msm finished");
     // ---- assembly (host).  The three products that involve only the CRS were computed while the GPU was busy (above);
     //      everything in G1 is assembled before waiting for the G2 multi-exponentiation, whose tail it overlaps.
@@ -350,7 +352,7 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
     G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
     lap("G1 side assembled");
-    if (!g2_done && msm_job_finish(crs->job_b2, nullptr, &Bt2)) return ZKG_ERROR;
+    if (g2_tail.get()) return ZKG_ERROR;
     lap("G2 msm finished");
     G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
     size_t off = 0;
