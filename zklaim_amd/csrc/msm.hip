@@ -332,11 +332,14 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
     const uint32_t base = ch * RED_CHUNK + t * RED_L;
     // lane-local running sums: S = sum_j X_j, T0 = sum_j j*X_j
     XYZZ<F> run = XYZZ<F>::inf(), T0 = XYZZ<F>::inf();
+    XYZZ<F> cur = (base + RED_L - 1 < B) ? X[base + RED_L - 1] : XYZZ<F>::inf();
     for (int j = RED_L - 1; j >= 1; --j) {
-        if (base + j < B) xyzz_add_quad(run, X[base + j], q);
+        XYZZ<F> nxt = (base + j - 1 < B) ? X[base + j - 1] : XYZZ<F>::inf();      // next bucket arrives under the two additions
+        xyzz_add_quad(run, cur, q);
         xyzz_add_quad(T0, run, q);
+        cur = nxt;
     }
-    if (base < B) xyzz_add_quad(run, X[base], q);
+    xyzz_add_quad(run, cur, q);
     // inclusive suffix scan of S over logical lanes (Hillis-Steele through LDS): Q_t = sum_{u>=t} S_u
     XYZZ<F> Q = run;
     for (uint32_t d = 1; d < RED_LANES; d <<= 1) {

@@ -5,21 +5,22 @@
 // r1cs_gg_ppzksnark_prover (/root/reference/zklaim/snark.cpp:126).
 //
 // Shape: the log2(N) butterfly stages are cut into passes of R <= 8 stages.  One workgroup
-// stages a tile of 2^R rows x CW columns (2048 elements = 64 KiB) in LDS, runs its R stages there
-// and writes the tile back, so a 2^20 transform touches HBM 3 times instead of 20.  The
+// stages a tile of 2^R rows x CW columns (512 or 1024 elements = 16 / 32 KiB, so several tiles share a CU) in LDS, runs its
+// R stages there and writes the tile back, so a 2^20 transform touches HBM 3 times instead of 20.  The
 // bit-reversal permutation is folded into the first pass's gather (reads stay CW*32 B contiguous),
 // coset / 1/N scalings are folded into the first load / last store.  Twiddles come from a
 // per-domain table omega^i (i < N/2) that stays L2/MALL resident.
 // MFMA is not used: the work is 254-bit modular multiplication on the integer VALU.
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
 namespace zk {
 
 static constexpr int NTT_THREADS = 512;
-static constexpr int NTT_TILE_LOG = 11;          // 2048 elements per workgroup tile
+static const int NTT_TILE_LOG_FORCE = getenv("ZKG_NTT_TILE_LOG") ? atoi(getenv("ZKG_NTT_TILE_LOG")) : 0;   // tuning aid
 static constexpr int NTT_MAX_R = 8;
 
 struct alignas(16) U4 { uint32_t a, b, c, d; };
@@ -171,6 +172,9 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
     if (batch > 1 && !scratch) { set_error("ntt: a batched transform needs its own scratch"); return ZKG_ERROR; }
     const size_t N = (size_t)1 << n;
+    // elements per workgroup tile, measured (MI355X): 512 up to 2^18 (0.058 ms against 0.099 ms with 2048-element tiles: four
+    // times as many workgroups and 4+ of them per CU, so one tile's loads run under another's butterflies), 1024 above
+    const int NTT_TILE_LOG = NTT_TILE_LOG_FORCE ? NTT_TILE_LOG_FORCE : (n <= 18 ? 9 : 10);
     unsigned npass = (n + NTT_MAX_R - 1) / NTT_MAX_R;
     if (n <= (unsigned)NTT_TILE_LOG) npass = 1;
     unsigned base = n / npass, extra = n % npass;
