@@ -13,6 +13,7 @@
 // MFMA is not used: the work is 254-bit modular multiplication on the integer VALU.
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -37,7 +38,7 @@ ZK_D uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (3
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     extern __shared__ U4 smem[];
     const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = 2 * CW + 1;   // +1 x 16 B pad per row
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, nthr = blockDim.x;         // one thread per butterfly of a stage
     A.src += (size_t)blockIdx.y * A.src_batch_stride; A.dst += (size_t)blockIdx.y * A.dst_batch_stride;
     const uint32_t s1 = A.s0 + A.R;
     const uint32_t lo_mask = (1u << A.s0) - 1;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     auto lds_st = [&](uint32_t row, uint32_t c, const Fr &r) { U4 *p = &smem[row * stride + 2 * c]; p[0] = *reinterpret_cast<const U4 *>(&r.v[0]); p[1] = *reinterpret_cast<const U4 *>(&r.v[4]); };
 
     // ---- load tile (c fastest: CW*32 B contiguous per row)
-    for (uint32_t e = tid; e < rows * CW; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {
         uint32_t c = e & (CW - 1), mid = e >> A.cw_log;
         size_t idx; uint32_t row;
         if (A.first) { idx = (size_t)mid * ((size_t)1 << (A.n_log - A.R)) + (size_t)tile * CW + c; row = bitrev(mid, A.R); }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     // ---- R butterfly stages in LDS
     for (uint32_t q = 0; q < A.R; ++q) {
         const uint32_t s = A.s0 + q, half = 1u << q;
-        for (uint32_t bf = tid; bf < (rows >> 1) * CW; bf += NTT_THREADS) {
+        for (uint32_t bf = tid; bf < (rows >> 1) * CW; bf += nthr) {
             uint32_t c = bf & (CW - 1), k = bf >> A.cw_log;
             uint32_t j = k & (half - 1), r0 = ((k >> q) << (q + 1)) | j, r1 = r0 + half;
             Fr u = lds_ld(r0, c), v = lds_ld(r1, c);
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     }
 
     // ---- store tile
-    for (uint32_t e = tid; e < rows * CW; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {
         uint32_t c, mid; size_t idx;
         if (A.first) { mid = e & (rows - 1); c = e >> A.R; idx = ((size_t)bitrev(tile * CW + c, A.n_log - A.R) << A.R) + mid; }
         else { c = e & (CW - 1); mid = e >> A.cw_log; uint32_t g = tile * CW + c; idx = ((size_t)(g >> A.s0) << s1) + ((size_t)mid << A.s0) + (g & lo_mask); }
@@ -172,9 +173,10 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
     if (batch > 1 && !scratch) { set_error("ntt: a batched transform needs its own scratch"); return ZKG_ERROR; }
     const size_t N = (size_t)1 << n;
-    // elements per workgroup tile, measured (MI355X): 512 up to 2^18 (0.058 ms against 0.099 ms with 2048-element tiles: four
-    // times as many workgroups and 4+ of them per CU, so one tile's loads run under another's butterflies), 1024 above
-    const int NTT_TILE_LOG = NTT_TILE_LOG_FORCE ? NTT_TILE_LOG_FORCE : (n <= 18 ? 9 : 10);
+    // elements per workgroup tile, measured (MI355X): 512 up to 2^20 (2^18: 0.057 ms against 0.099 ms with 2048-element tiles:
+    // four times as many workgroups and 4+ of them per CU, so one tile's loads run under another's butterflies), 1024 above;
+    // one thread per butterfly of a stage
+    const int NTT_TILE_LOG = NTT_TILE_LOG_FORCE ? NTT_TILE_LOG_FORCE : (n <= 20 ? 9 : 10);
     unsigned npass = (n + NTT_MAX_R - 1) / NTT_MAX_R;
     if (n <= (unsigned)NTT_TILE_LOG) npass = 1;
     unsigned base = n / npass, extra = n % npass;
@@ -200,7 +202,8 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
         size_t tiles = (N >> R) >> A.cw_log;
         size_t rows = (size_t)1 << R, CW = (size_t)1 << A.cw_log;
         size_t lds = rows * (2 * CW + 1) * 16;
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, batch), dim3(NTT_THREADS), lds, s, A);
+        unsigned threads = (unsigned)std::min<size_t>(NTT_THREADS, std::max<size_t>(64, rows * CW / 2));
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, batch), dim3(threads), lds, s, A);
         if (hipGetLastError() != hipSuccess) { set_error("ntt pass launch failed"); return ZKG_ERROR; }
         s0 += R;
     }
