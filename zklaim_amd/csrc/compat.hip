@@ -42,16 +42,23 @@ int ensure_init() {
     g_inited = true;
     return 0;
 }
-uint64_t digest(const unsigned char *p, size_t n) {            // FNV-1a over the head, the tail and 256 strided 4 KiB pages of the blob
+// Cache key of a pk blob: FNV-style mixing, 8 bytes at a time, over the head, the tail and 128 strided 512-byte windows (80 KB of a
+// 10-200 MB blob: two different keys differ in every group element, so any window tells them apart; the size is mixed in too).
+uint64_t digest(const unsigned char *p, size_t n) {
     uint64_t h = 1469598103934665603ull;
-    auto eat = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi && i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } };
-    if (n <= (1u << 21)) eat(0, n);
+    auto eat = [&](size_t lo, size_t hi) {
+        if (hi > n) hi = n;
+        size_t i = lo;
+        for (; i + 8 <= hi; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+        for (; i < hi; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    };
+    if (n <= (1u << 16)) eat(0, n);
     else {
-        eat(0, 1 << 16); eat(n - (1 << 16), n);
-        size_t step = n / 256;
-        for (size_t k = 1; k < 256; ++k) eat(k * step, k * step + 4096);
+        eat(0, 8192); eat(n - 8192, n);
+        size_t step = n / 128;
+        for (size_t k = 1; k < 128; ++k) eat(k * step, k * step + 512);
     }
-    return h ^ n;
+    return h ^ (n * 0x9E3779B97F4A7C15ull);
 }
 void random_fr_mont(uint64_t out[4]) {
     std::random_device rd;

@@ -23,7 +23,7 @@ struct Bit {
     bool is_const() const { return konst >= 0; }
     Bit operator!() const { Bit b = *this; if (is_const()) b.konst = 1 - konst; else b.neg = !neg; return b; }
     LC lc() const { if (is_const()) return LC::constant((uint64_t)konst); return neg ? LC::constant(1) - LC(v) : LC(v); }
-    bool value(const Builder &pb) const { if (is_const()) return konst != 0; bool x = pb.nz[v] != 0; return neg ? !x : x; }
+    bool value(const Builder &pb) const { if (is_const()) return konst != 0; bool x = pb.is_nonzero(v); return neg ? !x : x; }
 };
 
 inline Bit new_bit(Builder &pb, bool value) { Var v = pb.alloc(); pb.set_bit(v, value); return Bit::var(v); }
@@ -144,7 +144,7 @@ inline void enforce_packing(Builder &pb, const std::vector<Var> &bits, size_t lo
 }
 inline void assign_packing(Builder &pb, const std::vector<Var> &bits, size_t lo, size_t hi, Var packed) {
     Fr s = Fr::zero(), w = Fr::one();
-    for (size_t i = lo; i < hi; ++i) { if (pb.nz[bits[i]]) s += w; w = w.dbl(); }
+    for (size_t i = lo; i < hi; ++i) { if (pb.is_nonzero(bits[i])) s += w; w = w.dbl(); }
     pb.set(packed, s);
 }
 

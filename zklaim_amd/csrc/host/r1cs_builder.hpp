@@ -35,11 +35,20 @@ struct Builder {
     std::vector<Constraint> cons;
     uint32_t num_inputs = 0;
     bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
+    // A view allocates from a pre-sized range [cursor, cursor_end) of its root's storage and reads / writes values there: the
+    // per-payload sub-circuits of a witness-only pass are independent and run on separate threads through views.
+    Builder *root = nullptr; uint32_t cursor = 0, cursor_end = 0;
     Builder() { val.push_back(Fr::one()); nz.push_back(1); }
+    static Builder view_of(Builder &r, uint32_t begin, uint32_t end) { Builder v; v.root = &r; v.cursor = begin; v.cursor_end = end; v.recording = false; return v; }
     void reserve(size_t nvars) { val.reserve(nvars + 1); nz.reserve(nvars + 1); }
-    Var alloc() { val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1); }
-    void set(Var v, const Fr &x) { val[v] = x; nz[v] = !x.is_zero(); }
-    void set_bit(Var v, bool b) { val[v] = b ? Fr::one() : Fr::zero(); nz[v] = b; }
+    uint32_t extend(size_t count) { uint32_t first = (uint32_t)val.size(); val.resize(val.size() + count, Fr::zero()); nz.resize(nz.size() + count, 0); return first; }
+    Var alloc() {
+        if (root) return cursor < cursor_end ? cursor++ : (cursor++, 0);     // overrun is detected by the caller (cursor > cursor_end)
+        val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1);
+    }
+    void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = !x.is_zero(); }
+    void set_bit(Var v, bool b) { Builder &r = root ? *root : *this; r.val[v] = b ? Fr::one() : Fr::zero(); r.nz[v] = b; }
+    bool is_nonzero(Var v) const { return (root ? root : this)->nz[v] != 0; }
     std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
     void set_input_sizes(uint32_t n) { num_inputs = n; }
     uint32_t num_variables() const { return (uint32_t)val.size() - 1; }

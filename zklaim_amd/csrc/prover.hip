@@ -339,18 +339,18 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
             set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
         }
     }
-    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr)) return ZKG_ERROR;
-    // H and B_g2 end last, in either order: B_g2's host tail (chunk sums, 255 G2 doublings: ~0.3 ms) runs on a helper thread
-    // while this one finishes H and assembles everything that lives in G1
+    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing.
+    //      The three products that involve only the CRS were computed above.  A and B_g1 end early: s*A + r*B_1 - rs*delta (two
+    //      254-bit scalar multiplications, ~0.2 ms) is formed while H is still on the GPU; B_g2's host tail (chunk sums and 255 G2
+    //      doublings, ~0.3 ms) runs on a helper thread.
     auto g2_tail = std::async(std::launch::async, [&] { return msm_job_finish(crs->job_b2, nullptr, &Bt2); });
-    int rc_h = msm_job_finish(crs->job_h, &Ht, nullptr);
-    if (rc_h) { (void)g2_tail.get(); return ZKG_ERROR; }
-    lap("4 G1 msm finished");
-    // ---- assembly (host).  The three products that involve only the CRS were computed while the GPU was busy (above);
-    //      everything in G1 is assembled before waiting for the G2 multi-exponentiation, whose tail it overlaps.
+    if (msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr)) { (void)g2_tail.get(); return ZKG_ERROR; }
     G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
     G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
-    G1 gC = Ht; gC.add(Lt); gC.add(gA.mul(sc, 8)); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
+    G1 gC = gA.mul(sc, 8); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
+    lap("s*A + r*B1 - rs*delta");
+    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_h, &Ht, nullptr)) { (void)g2_tail.get(); return ZKG_ERROR; }
+    gC.add(Lt); gC.add(Ht);                                                 // C = H_t + L_t + s A + r B_1 - rs delta
     lap("G1 side assembled");
     if (g2_tail.get()) return ZKG_ERROR;
     lap("G2 msm finished");

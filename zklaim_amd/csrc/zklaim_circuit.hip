@@ -12,7 +12,10 @@
 #include "../../include/zkg.h"
 #include "../../include/zklaim_abi.h"
 #include "host/gadgets.hpp"
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 using namespace zk;
 using namespace zk::circuit;
@@ -53,13 +56,30 @@ std::vector<Var> byte_lsb_first(const std::vector<Var> &bits) {
 struct zkg_circuit {
     Builder pb;
     Builder::Csr A, B, C;
-    std::vector<uint64_t> witness;
     bool has_witness = false;
 };
+
+// The variable storage of a finished circuit (18 MB at 20 payloads) is handed to the next one: a prover calls this once per proof,
+// and fresh pages cost more than the witness pass itself.
+namespace {
+std::mutex g_store_mu; std::vector<Fr> g_spare_val; std::vector<uint8_t> g_spare_nz;
+void take_storage(Builder &pb) {
+    std::lock_guard<std::mutex> lk(g_store_mu);
+    if (g_spare_val.capacity()) { g_spare_val.clear(); g_spare_nz.clear(); pb.val.swap(g_spare_val); pb.nz.swap(g_spare_nz); pb.val.push_back(Fr::one()); pb.nz.push_back(1); }
+}
+void give_storage(Builder &pb) {
+    std::lock_guard<std::mutex> lk(g_store_mu);
+    if (pb.val.capacity() > g_spare_val.capacity()) { g_spare_val.swap(pb.val); g_spare_nz.swap(pb.nz); }
+}
+}  // namespace
 
 static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool witness_only = false) {
     zkg_circuit *ck = new zkg_circuit();
     Builder &pb = ck->pb;
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg circuit] %-28s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
+    take_storage(pb);
     pb.recording = !witness_only;                           // proving: the resident key already holds the constraint system
     pb.reserve(28000 * (ctx->num_of_payloads + 1));
     const size_t k = ctx->num_of_payloads;
@@ -114,6 +134,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         for (size_t c = 0; c < 64 * k; ++c) assign_packing(pb, OPS, c * 8, (c + 1) * 8, opsvals[c]);
     }
 
+    lap("allocation + public values");
     // ---- constraints (zklaim_gadget.cpp:583-699)
     for (size_t c = 0; c < n_inputs; ++c)                                       // unpack_inputs, with booleanity of every public bit
         enforce_packing(pb, input_as_bits, c * FR_CAPACITY, std::min(input_bits, (c + 1) * FR_CAPACITY), input_fe[c], true);
@@ -123,7 +144,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         for (size_t c = 0; c < 8 * k; ++c) enforce_packing(pb, REF, c * 64, (c + 1) * 64, refvals[c], false);
         for (size_t c = 0; c < 64 * k; ++c) enforce_packing(pb, OPS, c * 8, (c + 1) * 8, opsvals[c], false);
     }
-    for (size_t i = 0; i < k; ++i) {
+    auto payload_gadgets = [&](Builder &pb, size_t i) {                           // the per-payload sub-circuit; `pb` may be a view
         for (Var v : r_bits[i]) pb.enforce_boolean(v);                          // digest_variable r: booleanity
         for (int j = 0; j < 5; ++j) {                                           // comparison_gadget(64, data_j, refvals[j + 8 i], less, less_or_eq)
             Comparison cmp = comparison_alloc(pb, 64, leq[i][j]);
@@ -154,13 +175,27 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         block[384] = Bit::one();                                                // 0x80
         block[512 - 9] = Bit::one(); block[512 - 8] = Bit::one();              // length 384 = 0x0180, big-endian in the last 64 bits
         sha256_compress_from_iv(pb, block, h_bits[i]);
+    };
+    if (witness_only && k > 1) {
+        // Witness only: the k sub-circuits allocate the same number of variables each and touch disjoint ranges, so payload 0 runs
+        // here (and measures that number) and payloads 1..k-1 run on the host thread pool through views of the pre-sized storage.
+        const uint32_t before = pb.num_variables();
+        payload_gadgets(pb, 0);
+        const uint32_t per = pb.num_variables() - before;
+        const uint32_t first = pb.extend((size_t)per * (k - 1));
+        std::vector<char> bad(k, 0);
+        host_parallel_for((int)k - 1, [&](int t) {
+            Builder v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
+            payload_gadgets(v, (size_t)t + 1);
+            bad[t + 1] = v.cursor != v.cursor_end;
+        });
+        for (char b : bad) if (b) { delete ck; set_error("zklaim circuit: payload sub-circuits differ in size"); return nullptr; }
+    } else {
+        for (size_t i = 0; i < k; ++i) payload_gadgets(pb, i);
     }
+    lap("payload sub-circuits");
     if (pb.recording) pb.export_csr(ck->A, ck->B, ck->C);
-    if (with_witness) {
-        ck->has_witness = true;
-        ck->witness.resize((size_t)pb.num_variables() * 4);
-        for (uint32_t v = 1; v <= pb.num_variables(); ++v) memcpy(&ck->witness[4 * (size_t)(v - 1)], pb.val[v].v, 32);
-    }
+    ck->has_witness = with_witness;             // the witness is pb.val[1..] itself: Fr is the ABI's 4 x u64 Montgomery element
     return ck;
 }
 
@@ -175,7 +210,7 @@ zkg_circuit *zkg_zklaim_witness_new(const zklaim_ctx *ctx) {
     if (!ctx) { set_error("zkg_zklaim_witness_new: null ctx"); return nullptr; }
     return build_zklaim(ctx, true, true);
 }
-void zkg_circuit_free(zkg_circuit *c) { delete c; }
+void zkg_circuit_free(zkg_circuit *c) { if (c) give_storage(c->pb); delete c; }
 
 int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
     if (!c || !out) return ZKG_ERROR;
@@ -186,7 +221,10 @@ int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
     out->c_rowptr = c->C.rowptr.data(); out->c_col = c->C.col.data(); out->c_val = c->C.val.data();
     return ZKG_OK;
 }
-const uint64_t *zkg_circuit_witness(const zkg_circuit *c) { return (c && c->has_witness) ? c->witness.data() : nullptr; }
+const uint64_t *zkg_circuit_witness(const zkg_circuit *c) {
+    static_assert(sizeof(Fr) == 32, "Fr must be the ABI's 32-byte element");
+    return (c && c->has_witness) ? reinterpret_cast<const uint64_t *>(c->pb.val.data() + 1) : nullptr;
+}
 int zkg_circuit_is_satisfied(const zkg_circuit *c) { return c && c->has_witness && c->pb.recording && c->pb.is_satisfied() ? 1 : 0; }
 uint32_t zkg_circuit_num_variables(const zkg_circuit *c) { return c ? c->pb.num_variables() : 0; }
 long zkg_circuit_first_unsatisfied(const zkg_circuit *c) { return c ? (long)c->pb.first_unsatisfied() : -2; }
