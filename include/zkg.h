@@ -192,6 +192,9 @@ size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
 int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs,
                        const uint8_t *proof, size_t proof_len);
 int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]);   /* e(a*G1, b*G2), for bilinearity tests */
+/* test hook: Frobenius maps and the last chunk of the final exponentiation against plain square-and-multiply by q^k and by
+ * the integer e (nlimbs x u32, little-endian); 0 = all agree */
+int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs);
 
 /* ---- the reference's own seam (zklaim.h:257-259, libsnark_wrapper.cpp:195-276), same names and return codes, on
  *      zklaim's zklaim_ctx (include/zklaim_abi.h): the three functions zklaim.c:77-91 calls.                               */

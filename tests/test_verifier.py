@@ -23,6 +23,19 @@ def test_pairing_bilinear_and_nondegenerate():
     assert e(R - 1, R - 1) == e(1, 1)
 
 
+def test_final_exponentiation_chain_and_frobenius():
+    """libff's last chunk (Fuentes-Castaneda chain) raises to lambda_0 + lambda_1 q + lambda_2 q^2 + lambda_3 q^3 =
+    2z(6z^2 + 3z + 1) (q^4 - q^2 + 1)/r; the coefficient-wise Frobenius maps equal powering by q, q^2, q^3"""
+    z = 4965661367192848881
+    assert 36 * z**4 + 36 * z**3 + 24 * z**2 + 6 * z + 1 == Q and 36 * z**4 + 36 * z**3 + 18 * z**2 + 6 * z + 1 == R
+    lam = [12 * z**3 + 12 * z**2 + 6 * z + 1, 12 * z**3 + 6 * z**2 + 4 * z, 12 * z**3 + 6 * z**2 + 6 * z, 12 * z**3 + 6 * z**2 + 4 * z - 1]
+    e = sum(l * Q**i for i, l in enumerate(lam))
+    hard = (Q**4 - Q**2 + 1) // R
+    assert (Q**4 - Q**2 + 1) % R == 0 and e == 2 * z * (6 * z * z + 3 * z + 1) * hard
+    assert zkg.pairing_selfcheck(e) == 0
+    assert zkg.pairing_selfcheck(hard) == 16                 # the exact hard exponent is a different (equally valid) pairing value
+
+
 def ser_fq(x):
     return (x * MONT % Q).to_bytes(32, "little")
 

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
-    "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe",
+    "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
@@ -432,6 +432,13 @@ def pairing_probe(a, b):
     out = np.zeros(384, np.uint8)
     lib().zkg_pairing_probe(_p(_u64(a)), _p(_u64(b)), _p(out))
     return out.tobytes()
+
+
+def pairing_selfcheck(exponent):
+    """0 when the Frobenius maps and the final exponentiation's last chunk agree with square-and-multiply (exponent: Python int)"""
+    n = (exponent.bit_length() + 31) // 32
+    e = np.array([(exponent >> (32 * i)) & 0xFFFFFFFF for i in range(n)], np.uint32)
+    return lib().zkg_pairing_selfcheck(e.ctypes.data_as(C.c_void_p), n)
 
 
 def libsnark_trusted_setup(ctx): return lib().libsnark_trusted_setup(C.byref(ctx))

@@ -10,6 +10,7 @@
 // bilinear, non-degenerate pairing makes the Groth16 check sound and complete; GT values are NOT claimed to equal libff's
 // representation bit for bit (libff may differ by a fixed unit power), which only matters for exchanging vk blobs.
 #pragma once
+#include <vector>
 #include "../curve.cuh"
 
 namespace zk { namespace pairing {
@@ -66,60 +67,116 @@ struct Fq12 {
     }
 };
 
-// the line through T (slope lambda on the twist) evaluated at P, as a sparse Fq12: yP + (-lambda xP) w + (lambda xT - yT) w^3
-inline Fq12 line(const Fq2 &lambda, const G2Affine &T, const G1Affine &P) {
-    Fq12 l; l.c0 = {Fq2{P.y, Fq::zero()}, Fq2::zero(), Fq2::zero()};
-    l.c1 = {scale(lambda, P.x).neg(), lambda * T.x - T.y, Fq2::zero()};
-    return l;
-}
+// the line through T (slope lambda on the twist) evaluated at P is the sparse Fq12  yP + (-lambda xP) w + (lambda xT - yT) w^3
 inline G2Affine frobenius_twist(const G2Affine &Q, const Fq2 &gx, const Fq2 &gy, bool conjugate_coords) {
     return conjugate_coords ? G2Affine{conj(Q.x) * gx, conj(Q.y) * gy} : G2Affine{Q.x * gx, Q.y * gy};
 }
 
-// Miller function of the optimal ate pairing (no final exponentiation); P, Q finite
-inline Fq12 miller_loop(const G1Affine &P, const G2Affine &Q) {
+// gamma_1 = xi^((q-1)/6) (the constant the Miller loop's pi(Q) uses as well)
+inline Fq2 gamma1() {
     static const uint32_t E_QM1_6[8] = {0x2414d4e1u, 0x34b01759u, 0xe6bda1c2u, 0xee9591c2u, 0xc0403964u, 0xf40d60f3u, 0xd032f006u, 0x0810b7bdu};
-    const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;   // 6z+2 = 29793968203157093288 (65 bits)
-    Fq12 f = Fq12::one();
-    G2Affine T = Q;
-    auto dbl_step = [&]() {
-        Fq2 xx = T.x.sqr();
-        Fq2 lambda = (xx.dbl() + xx) * T.y.dbl().inverse();
-        f = f.sqr() * line(lambda, T, P);
-        Fq2 x3 = lambda.sqr() - T.x.dbl();
-        T = {x3, lambda * (T.x - x3) - T.y};
+    Fq2 g1 = Fq2::one(), base = xi();
+    for (int i = 8 * 32 - 1; i >= 0; --i) { g1 = g1.sqr(); if ((E_QM1_6[i >> 5] >> (i & 31)) & 1u) g1 = g1 * base; }
+    return g1;
+}
+// f * l for a line l = a + b w + c w^3 (a = yP in Fq, b, c in Fq2): in the tower l = (a, 0, 0) + (b, c, 0) w.
+inline Fq12 mul_by_line(const Fq12 &f, const Fq &a, const Fq2 &b, const Fq2 &c) {
+    // f.c0 * (a,0,0) and f.c1 * (a,0,0) are coefficient scalings; X * (b, c, 0) is a sparse Fq6 product (v^3 = xi)
+    auto sparse = [&](const Fq6 &x) {                        // x * (b + c v)
+        Fq2 x0b = x.c0 * b, x1c = x.c1 * c;
+        Fq2 mid = (x.c0 + x.c1) * (b + c) - x0b - x1c;       // x0 c + x1 b
+        return Fq6{x0b + mul_xi(x.c2 * c), mid, x1c + x.c2 * b};
     };
-    auto add_step = [&](const G2Affine &R_) {
-        Fq2 lambda = (R_.y - T.y) * (R_.x - T.x).inverse();
-        f = f * line(lambda, T, P);
-        Fq2 x3 = lambda.sqr() - T.x - R_.x;
-        T = {x3, lambda * (T.x - x3) - T.y};
-    };
-    for (int i = 63; i >= 0; --i) {                          // bit 64 is the leading one
-        dbl_step();
-        if ((S >> i) & 1) add_step(Q);
-    }
-    // gamma = xi^((q-1)/6): pi(Q) = (conj(x) gamma^2, conj(y) gamma^3); pi^2(Q) = (x N^2, y N^3) with N = gamma conj(gamma) in Fq
-    Fq2 g1 = Fq2::one(); { Fq2 base = xi(); for (int i = 8 * 32 - 1; i >= 0; --i) { g1 = g1.sqr(); if ((E_QM1_6[i >> 5] >> (i & 31)) & 1u) g1 = g1 * base; } }
-    Fq2 g2 = g1.sqr(), g3 = g2 * g1;
-    Fq2 n1 = g1 * conj(g1), n2 = n1.sqr(), n3 = n2 * n1;
-    G2Affine Q1 = frobenius_twist(Q, g2, g3, true);
-    G2Affine Q2 = frobenius_twist(Q, n2, n3, false);
-    add_step(Q1);
-    add_step(G2Affine{Q2.x, Q2.y.neg()});
-    return f;
+    auto scl = [&](const Fq6 &x) { return Fq6{scale(x.c0, a), scale(x.c1, a), scale(x.c2, a)}; };
+    // (f0 + f1 w)(A + B w) = f0 A + f1 B v + (f0 B + f1 A) w   with A = (a,0,0), B = (b,c,0), w^2 = v
+    return {scl(f.c0) + sparse(f.c1).mul_by_v(), sparse(f.c0) + scl(f.c1)};
 }
 
-inline Fq12 final_exponentiation(const Fq12 &f) {
-    static const uint32_t E_Q2P1[16] = {0x275d69b2u, 0x3b5458a2u, 0x09eac101u, 0xa602072du, 0x6d96cadcu, 0x4a50189cu, 0x7a1242c8u, 0x04689e95u,
-                                        0x34c6b38du, 0x26edfa5cu, 0x16375606u, 0xb00b8551u, 0x0348d21cu, 0x599a6f7cu, 0x763cbf9cu, 0x0925c4b8u};
-    static const uint32_t E_HARD[24] = {0xccdf42b1u, 0xe81bb482u, 0xf49c36d4u, 0x5abf5cc4u, 0x1da014fdu, 0xf1154e7eu, 0x87cdbacfu, 0xdcc7b44cu,
-                                        0x954bcf8au, 0xaaa441e3u, 0xd5095f23u, 0x6b887d56u, 0xf3fd90c6u, 0x79581e16u, 0xd189227du, 0x3b1b1355u,
-                                        0x61876f6bu, 0x4e529a58u, 0xd5b12278u, 0x6c0eb522u, 0x83177fafu, 0x331ec151u, 0x0b0759adu, 0x01baaa71u};
-    Fq12 g = f.conjugate() * f.inverse();                    // f^(q^6 - 1)
-    g = g.pow(E_Q2P1, 16);                                    // ^(q^2 + 1)
-    return g.pow(E_HARD, 24);                                 // ^((q^4 - q^2 + 1)/r)
+// Product of the Miller functions of the optimal ate pairing over several (P_j, Q_j) (no final exponentiation); all points
+// finite.  The loops run in lock-step: one squaring of f per step for all pairs and ONE field inversion per step (the slopes'
+// denominators are inverted together), which is what a verifier with three pairings needs.
+inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
+    const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;   // 6z+2 = 29793968203157093288 (65 bits)
+    Fq12 f = Fq12::one();
+    std::vector<G2Affine> T(Q, Q + n);
+    std::vector<Fq2> den(n), pre(n);
+    auto invert_all = [&]() {                                // den[j] <- 1/den[j]
+        Fq2 run = Fq2::one();
+        for (int j = 0; j < n; ++j) { pre[j] = run; run = run * den[j]; }
+        Fq2 inv = run.inverse();
+        for (int j = n - 1; j >= 0; --j) { Fq2 d = inv * pre[j]; inv = inv * den[j]; den[j] = d; }
+    };
+    auto apply = [&](int j, const Fq2 &lambda, const Fq2 &x_other) {       // multiply the line in, move T_j along it
+        f = mul_by_line(f, P[j].y, scale(lambda, P[j].x).neg(), lambda * T[j].x - T[j].y);
+        Fq2 x3 = lambda.sqr() - T[j].x - x_other;
+        T[j] = {x3, lambda * (T[j].x - x3) - T[j].y};
+    };
+    auto dbl_step = [&]() {
+        for (int j = 0; j < n; ++j) den[j] = T[j].y.dbl();
+        invert_all();
+        f = f.sqr();
+        for (int j = 0; j < n; ++j) { Fq2 xx = T[j].x.sqr(); apply(j, (xx.dbl() + xx) * den[j], T[j].x); }
+    };
+    auto add_step = [&](const std::vector<G2Affine> &R_) {
+        for (int j = 0; j < n; ++j) den[j] = R_[j].x - T[j].x;
+        invert_all();
+        for (int j = 0; j < n; ++j) apply(j, (R_[j].y - T[j].y) * den[j], R_[j].x);
+    };
+    std::vector<G2Affine> Q0(Q, Q + n);
+    for (int i = 63; i >= 0; --i) {                          // bit 64 is the leading one
+        dbl_step();
+        if ((S >> i) & 1) add_step(Q0);
+    }
+    // gamma = xi^((q-1)/6): pi(Q) = (conj(x) gamma^2, conj(y) gamma^3); pi^2(Q) = (x N^2, y N^3) with N = gamma conj(gamma) in Fq
+    static const Fq2 g1 = gamma1();
+    static const Fq2 g2 = g1.sqr(), g3 = g2 * g1, n1 = g1 * conj(g1), n2 = n1.sqr(), n3 = n2 * n1;
+    std::vector<G2Affine> Q1(n), Q2(n);
+    for (int j = 0; j < n; ++j) {
+        Q1[j] = frobenius_twist(Q[j], g2, g3, true);
+        G2Affine t = frobenius_twist(Q[j], n2, n3, false);
+        Q2[j] = {t.x, t.y.neg()};
+    }
+    add_step(Q1);
+    add_step(Q2);
+    return f;
 }
+inline Fq12 miller_loop(const G1Affine &P, const G2Affine &Q) { return multi_miller_loop(&P, &Q, 1); }
+
+// x -> x^(q^k), k = 1, 2, 3.  Fq12 = Fq2[w]/(w^6 - xi): the coefficient a_i of w^i goes to conj^k(a_i) * gamma_k^i with
+// gamma_k = xi^((q^k - 1)/6): gamma_2 = gamma_1 conj(gamma_1) (in Fq), gamma_3 = gamma_2 gamma_1.
+inline Fq12 frobenius(const Fq12 &x, int k) {
+    static const Fq2 G1c = gamma1();
+    static const Fq2 G2c = G1c * conj(G1c), G3c = G2c * G1c;
+    const Fq2 g = k == 1 ? G1c : k == 2 ? G2c : G3c;
+    Fq2 pw[6]; pw[0] = Fq2::one(); for (int i = 1; i < 6; ++i) pw[i] = pw[i - 1] * g;
+    auto m = [&](const Fq2 &a, int i) { return ((k & 1) ? conj(a) : a) * pw[i]; };
+    // tower layout: c0 = (w^0, w^2, w^4), c1 = (w^1, w^3, w^5)
+    return {{m(x.c0.c0, 0), m(x.c0.c1, 2), m(x.c0.c2, 4)}, {m(x.c1.c0, 1), m(x.c1.c1, 3), m(x.c1.c2, 5)}};
+}
+// elt^z for the curve parameter z = 4965661367192848881 (libff alt_bn128_final_exponent_z; q and r are polynomials in z)
+inline Fq12 exp_by_z(const Fq12 &x) { static const uint32_t Z[2] = {0x4a6909f1u, 0x44e992b4u}; return x.pow(Z, 2); }
+inline Fq12 exp_by_neg_z(const Fq12 &x) { return exp_by_z(x).conjugate(); }     // unitary inverse: x is in the cyclotomic subgroup here
+
+// libff alt_bn128_final_exponentiation [UPSTREAM-RECALL]: first chunk f^((q^6 - 1)(q^2 + 1)), then the last chunk by the
+// Fuentes-Castaneda et al. chain, which raises to  lambda_0 + lambda_1 q + lambda_2 q^2 + lambda_3 q^3,
+//   lambda_0 = 12z^3 + 12z^2 + 6z + 1, lambda_1 = 12z^3 + 6z^2 + 4z, lambda_2 = 12z^3 + 6z^2 + 6z, lambda_3 = 12z^3 + 6z^2 + 4z - 1,
+// = 2z(6z^2 + 3z + 1) * (q^4 - q^2 + 1)/r: a fixed multiple of the exact hard exponent, so GT values agree with libff's
+// (the alpha_g1_beta_g2 element of a verification key) and not with a textbook reduced pairing.
+// tests/test_verifier.py checks the chain against a plain square-and-multiply by that integer.
+inline Fq12 final_exponentiation_first_chunk(const Fq12 &f) {
+    Fq12 a = f.conjugate() * f.inverse();                    // f^(q^6 - 1)
+    return frobenius(a, 2) * a;                              // ^(q^2 + 1)
+}
+inline Fq12 final_exponentiation_last_chunk(const Fq12 &elt) {
+    Fq12 A = exp_by_neg_z(elt), B = A.sqr(), C = B.sqr(), D = C * B;
+    Fq12 E = exp_by_neg_z(D), F = E.sqr(), G = exp_by_neg_z(F);
+    Fq12 H = D.conjugate(), I = G.conjugate();
+    Fq12 J = I * E, K = J * H, L = K * B, M = K * E, N = M * elt;
+    Fq12 O = frobenius(L, 1), P = O * N, Q = frobenius(K, 2), R = Q * P;
+    Fq12 S = elt.conjugate(), T = S * L, U = frobenius(T, 3);
+    return U * R;
+}
+inline Fq12 final_exponentiation(const Fq12 &f) { return final_exponentiation_last_chunk(final_exponentiation_first_chunk(f)); }
 
 inline Fq12 reduced_pairing(const G1Affine &P, const G2Affine &Q) {
     if (P.is_inf() || Q.is_inf()) return Fq12::one();

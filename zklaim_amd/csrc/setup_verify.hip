@@ -219,17 +219,22 @@ int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *pr
     if (!ser::get_g1(proof, pA) || !ser::get_g2(proof + 34, pB) || !ser::get_g1(proof + 100, pC)) return 1;     // is_well_formed
     // acc = IC_0 + sum_i input_i * IC_{i+1}
     G1 acc = G1::from_affine(ic0);
-    for (size_t k = 0; k < nidx; ++k) {
-        G1Affine p; if (!ser::get_g1(vals + 34 * k, p)) { set_error("vk blob: bad gamma_ABC point"); return 2; }
-        Fr x; memcpy(x.v, primary_input + 4 * idx[k], 32);
-        uint32_t e[8]; fr_limbs(x, e);
-        acc.add(G1::from_affine(p).mul(e, 8));
+    {   // each term (one point decompression, one 254-bit scalar multiplication) is independent: host thread pool
+        std::vector<G1> term(nidx); std::vector<char> bad(nidx, 0);
+        host_parallel_for((int)nidx, [&](int k) {
+            G1Affine p; if (!ser::get_g1(vals + 34 * (size_t)k, p)) { bad[k] = 1; return; }
+            Fr x; memcpy(x.v, primary_input + 4 * idx[k], 32);
+            uint32_t e[8]; fr_limbs(x, e);
+            term[k] = G1::from_affine(p).mul(e, 8);
+        });
+        for (size_t k = 0; k < nidx; ++k) { if (bad[k]) { set_error("vk blob: bad gamma_ABC point"); return 2; } acc.add(term[k]); }
     }
     // e(A, B) == e(alpha, beta) * e(acc, gamma) * e(C, delta)   <=>   FE( ML(A,B) * ML(-acc, gamma) * ML(-C, delta) ) == alpha_beta
     G1Affine accA = acc.to_affine();
-    Fq12 f = Fq12::one();
-    auto ml = [&](const G1Affine &P, const G2Affine &Q) { if (!P.is_inf() && !Q.is_inf()) f = f * pairing::miller_loop(P, Q); };
+    std::vector<G1Affine> Ps; std::vector<G2Affine> Qs;
+    auto ml = [&](const G1Affine &P, const G2Affine &Q) { if (!P.is_inf() && !Q.is_inf()) { Ps.push_back(P); Qs.push_back(Q); } };
     ml(pA, pB); ml(accA.neg(), gamma_g2); ml(pC.neg(), delta_g2);
+    Fq12 f = Ps.empty() ? Fq12::one() : pairing::multi_miller_loop(Ps.data(), Qs.data(), (int)Ps.size());   // three loops in lock-step
     return pairing::final_exponentiation(f) == alpha_beta ? 0 : 1;
 }
 
@@ -240,6 +245,22 @@ int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]
     G2Affine Q = G2::from_affine(g2_generator()).mul(eb, 8).to_affine();
     ser::put_fq12(out, pairing::reduced_pairing(P, Q));
     return 0;
+}
+
+// test hook: 0 when (1) x -> x^(q^k) by coefficient maps equals square-and-multiply by q^k (k = 1, 2, 3) and (2) the last chunk of the
+// final exponentiation equals square-and-multiply by the integer `e` (nlimbs x u32, little-endian); bit flags otherwise
+int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
+    uint32_t k3[8] = {3}, k5[8] = {5};
+    G1Affine P = G1::from_affine(g1_generator()).mul(k3, 8).to_affine();
+    G2Affine Q = G2::from_affine(g2_generator()).mul(k5, 8).to_affine();
+    Fq12 f = pairing::miller_loop(P, Q);
+    int bad = 0;
+    Fq12 x = f;
+    for (int k = 1; k <= 3; ++k) { x = x.pow(FqParams::P, 8); if (!(x == pairing::frobenius(f, k))) bad |= 1 << (k - 1); }
+    Fq12 g = pairing::final_exponentiation_first_chunk(f);
+    if (!(g.conjugate() * g == Fq12::one())) bad |= 8;                        // in the cyclotomic subgroup: g^(q^6) = g^-1
+    if (e && nlimbs > 0 && !(pairing::final_exponentiation_last_chunk(g) == g.pow(e, nlimbs))) bad |= 16;
+    return bad;
 }
 
 }  // extern "C"
