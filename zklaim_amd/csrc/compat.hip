@@ -8,6 +8,8 @@
 // :199-203,220-225,254-258), nothing is re-initialised per call, and the parsed key stays resident on the GPU between proofs
 // of the same ctx->pk instead of being re-parsed (:230).
 #include "common.hpp"
+#include <cstdio>
+#include <chrono>
 #include "../../include/zkg.h"
 #include "../../include/zklaim_abi.h"
 #include <cstdlib>
@@ -79,12 +81,17 @@ int libsnark_trusted_setup(zklaim_ctx *ctx) {
     if (!ctx) return ZKLAIM_ERROR;
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return ZKLAIM_ERROR;
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg seam setup] %-24s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     zkg_circuit *ck = zkg_zklaim_circuit_new(ctx, 0);             // generate_keypair: gadget + constraints only (snark.cpp:76-92)
     if (!ck) return ZKLAIM_ERROR;
+    lap("circuit built");
     zkg_r1cs cs;
     zkg_keypair *kp = zkg_circuit_r1cs(ck, &cs) == 0 ? zkg_groth16_setup(&cs, nullptr) : nullptr;
     zkg_circuit_free(ck);
     if (!kp) return ZKLAIM_ERROR;
+    lap("keypair generated");
     size_t vk_len = zkg_keypair_vk_blob(kp, nullptr, 0), pk_len = zkg_keypair_pk_blob(kp, nullptr, 0);
     unsigned char *vk = (unsigned char *)malloc(vk_len), *pk = (unsigned char *)malloc(pk_len);
     int rc = ZKLAIM_ERROR;
@@ -92,6 +99,7 @@ int libsnark_trusted_setup(zklaim_ctx *ctx) {
         ctx->vk = vk; ctx->vk_size = vk_len; ctx->pk = pk; ctx->pk_size = pk_len;                 // libsnark_wrapper.cpp:207-208
         rc = ZKLAIM_OK;
     } else { free(vk); free(pk); }
+    lap("blobs written");
     zkg_keypair_free(kp);
     return rc;
 }

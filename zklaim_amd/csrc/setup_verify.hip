@@ -11,6 +11,7 @@
 // step_radix2 domain for some sizes; this build always uses basic radix-2 domains).
 // Verifier: host pairing (host/pairing.hpp); the public input is folded into gamma_ABC with host scalar multiplications.
 #include "common.hpp"
+#include <chrono>
 #include "../../include/zkg.h"
 #include "host/serialize.hpp"
 #include <cstdio>
@@ -93,6 +94,9 @@ extern "C" {
 zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5 x 4 canonical limbs: t, alpha, beta, gamma, delta; NULL = random */) {
     if (!cs || !cs->a_rowptr || !cs->b_rowptr || !cs->c_rowptr) { set_error("zkg_groth16_setup: null constraint system"); return nullptr; }
     zkg_keypair *kp = new zkg_keypair();
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg setup] %-28s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     kp->n = cs->num_variables; kp->l = cs->num_inputs; kp->C = cs->num_constraints;
     const size_t n = kp->n, l = kp->l, C = kp->C;
     copy_csr(kp->rp[0], kp->col[0], kp->val[0], cs->a_rowptr, cs->a_col, cs->a_val, kp->C);
@@ -114,9 +118,11 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     Fr t, alpha, beta, gamma, delta;
     if (trapdoor) { t = fr_from_canonical(trapdoor); alpha = fr_from_canonical(trapdoor + 4); beta = fr_from_canonical(trapdoor + 8); gamma = fr_from_canonical(trapdoor + 12); delta = fr_from_canonical(trapdoor + 16); }
     else { t = random_fr(); alpha = random_fr(); beta = random_fr(); gamma = random_fr(); delta = random_fr(); }
+    lap("copy + swap");
     // ---- Lagrange coefficients u_i = L_i(t) and Z(t) on the chosen domain (closed forms, one batched inversion)
     Fr Zt; std::vector<Fr> u;
     if (domain_lagrange(shape, t, u, Zt)) { delete kp; return nullptr; }
+    lap("lagrange");
     // ---- QAP polynomials at t (r1cs_to_qap_instance_map_with_evaluation)
     std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
     for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
@@ -131,6 +137,7 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
         Fr abc = beta * At[i] + alpha * Bt[i] + Ct[i];
         if (i <= l) ICs[i] = abc * ginv; else Ls[i - l - 1] = abc * dinv;
     }
+    lap("qap evaluation + scalars");
     // ---- scalars -> points (GPU fixed-base batches)
     G1Affine g1 = g1_generator(); G2Affine g2 = g2_generator();
     std::vector<G1Affine> small1; std::vector<G2Affine> small2;
@@ -141,7 +148,9 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     if (!ok) { delete kp; return nullptr; }
     kp->alpha_g1 = small1[0]; kp->beta_g1 = small1[1]; kp->delta_g1 = small1[2];
     kp->beta_g2 = small2[0]; kp->delta_g2 = small2[1]; kp->gamma_g2 = small2[2];
+    lap("fixed-base batches (GPU)");
     kp->alpha_beta = pairing::reduced_pairing(kp->alpha_g1, kp->beta_g2);
+    lap("pairing");
     zkg_pk &v = kp->pk_view; memset(&v, 0, sizeof(v));
     v.cs.num_variables = kp->n; v.cs.num_inputs = kp->l; v.cs.num_constraints = kp->C;
     v.cs.a_rowptr = kp->rp[0].data(); v.cs.a_col = kp->col[0].data(); v.cs.a_val = kp->val[0].data();
