@@ -118,3 +118,18 @@ def test_msm_g2_larger_and_edges(zkg, oracle):
     assert np.array_equal(zkg.msm_g2(bases, sc), oracle.msm_g2(bases, sc))
     assert np.array_equal(zkg.msm_g2(bases[:0], sc[:0]), g2_jac_expected(None))          # empty
     assert np.array_equal(zkg.msm_g1(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)), g1_jac_expected(None))
+
+
+def test_size_limits_are_refused_not_truncated(zkg):
+    """maximum sizes: the sorted index list is 32-bit (n * windows < 2^32) and Fr has 2-adicity 28; anything larger is an error
+    before a single byte is touched (the device pointers below are never dereferenced)"""
+    import torch
+    d = torch.zeros(64, dtype=torch.int64, device="cuda")
+    with pytest.raises(zkg.ZkgError):
+        zkg.msm_g1_dev(d.data_ptr(), d.data_ptr(), 1 << 28)           # 2^28 points x 16 windows = 2^32 entries
+    with pytest.raises(zkg.ZkgError):
+        zkg.msm_g1_dev(d.data_ptr(), d.data_ptr(), 1 << 31)
+    with pytest.raises(zkg.ZkgError):
+        zkg.ntt_dev(d.data_ptr(), 29)
+    # the largest windows-per-point product that is accepted is exercised by bench.py at 2^20..2^23; here: 2^24 entries per window
+    # would need 1.6 GB of bases, so the positive side of the limit is covered by test_msm_full_size_properties
