@@ -76,6 +76,11 @@ def extras(zkg, torch, args, with_cpu):
     out["ntt_2p20"] = {"ms_per_transform": round(dt * 1e3, 4), "GBps_algorithmic": round(64 * n / dt / 1e9, 2), "bytes_per_element": 64,
                        "frac_of_hbm_peak": round(64 * n / dt / 1e9 / HBM_PEAK_GBPS, 5), "forward_inverse_roundtrip_exact": roundtrip_ok}
 
+    out["groth16_prove"] = prove_leg(zkg, torch, args, with_cpu)
+    return out
+
+
+def prove_leg(zkg, torch, args, with_cpu):
     # ---- Groth16 prove on zklaim's own credential circuit (zklaim_gadget rebuilt on the host, zklaim_amd/csrc/zklaim_circuit.hip):
     #      k payloads -> m = 2^logm (k = 8 -> 2^18, BASELINE configs[3]; k = 20 -> 2^20, the north-star size).  Keys come from the
     #      product's GPU generator with a fixed trapdoor; (r, s) fixed; the CPU oracle proves the same instance for byte parity.
@@ -133,8 +138,7 @@ def extras(zkg, torch, args, with_cpu):
         g["proof_bytes_match_cpu"] = bool(rc_o == 0 and proof_o == proof)
         g["speedup_vs_cpu_1core"] = round(cpu_dt / dt, 1)
     crs.free(); kp.free(); ck.free()
-    out["groth16_prove"] = g
-    return out
+    return g
 
 
 def main():
@@ -275,6 +279,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         line["extras"] = extras(zkg, torch, args, not args.no_cpu_baseline)
         line["proofs_per_sec"] = line["extras"]["groth16_prove"]["proofs_per_sec"]          # the other half of BASELINE.json's metric
+    if (world > 1 or (use_dist and os.environ.get("ZKG_BENCH_TEST_REPLICAS"))) and not args.no_extras:      # the env switch lets one GPU rehearse this branch
+        # the prover does not shard (replicas only): every rank proves the same 8-payload credential on its own GPU
+        # with its own resident key; the job's proofs/sec is the sum over ranks
+        try:
+            g = prove_leg(zkg, torch, args, False)
+            pps = torch.tensor([g["proofs_per_sec"], 1.0], dtype=torch.float64, device="cuda")
+        except Exception as exc:                                     # never lose the headline line over the extra
+            print("prove replicas failed:", exc, file=sys.stderr)
+            pps = torch.tensor([0.0, 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pps, op=dist.ReduceOp.SUM)
+        if rank == 0 and int(pps[1].item()) == world:
+            line["proofs_per_sec"] = round(float(pps[0].item()), 3)
+            line["proofs_per_sec_note"] = f"{world} independent prover replicas (one per GPU), zklaim gadget, 8 payloads, m = 2^18"
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
