@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOGN, help="log2 points per GPU (default: BASELINE config 2)")
+    ap.add_argument("--sharding", choices=["points", "windows"], default="points",
+                    help="multi-GPU partition: points (default; each rank owns 2^logn points) or windows (every rank holds all N*2^logn points "
+                         "and owns every N-th Pippenger window; SURVEY.md section 8e's variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
     ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 38 payloads (the north star's 2^20-constraint case)")
@@ -178,9 +181,12 @@ def main():
     arch, cus = zkg.device_info()
 
     n = 1 << args.logn
+    by_windows = args.sharding == "windows" and world > 1
+    if by_windows:
+        n *= world                                  # every rank holds the whole job's points (same seeds everywhere) and owns W/world windows
     # ---- synthetic resident inputs: bases k_i*G1 built on device by the product's fixed-base kernel
-    ks = splitmix_fr(n, SEED + 1 + 0x100 * rank)
-    sc = splitmix_fr(n, SEED + 2 + 0x100 * rank)
+    ks = splitmix_fr(n, SEED + 1 + (0 if by_windows else 0x100 * rank))
+    sc = splitmix_fr(n, SEED + 2 + (0 if by_windows else 0x100 * rank))
     d_k = torch.from_numpy(ks.view(np.int64)).cuda()
     d_bases = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), n, d_bases.data_ptr())
@@ -190,7 +196,11 @@ def main():
     from zklaim_amd import dist as zdist
 
     def step():
-        part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)       # normalised partial (host)
+        if by_windows:
+            w0, ws = zdist.window_shard(world, rank)
+            part = zkg.msm_g1_windows_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, w0, ws, stream=stream)
+        else:
+            part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)   # normalised partial (host)
         return zdist.combine_partials_g1(part, device="cuda") if use_dist else part
 
     def fence():
@@ -213,7 +223,8 @@ def main():
         dt = float(t.item())
     kern_ms, launches = zkg.timing_dominant_ms()
 
-    total_points = n * world
+    total_points = n if by_windows else n * world
+    n = n // world if by_windows else n            # per-rank share of the points, for the per-launch algorithmic bytes below
     ms_per_step = dt / args.steps * 1e3
     value = BYTES_PER_POINT * total_points / (dt / args.steps) / 1e9
     achieved = BYTES_PER_POINT * n / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
@@ -224,7 +235,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u32x8-montgomery (254-bit Fq/Fr)", "data": "synthetic",
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
-                   "sharding": "points sharded per rank; all-gather of normalised partial points + EC add" if world > 1 else "single GPU"},
+                   "sharding": ("windows sharded per rank (every rank holds all points); " if by_windows else "points sharded per rank; ") + "all-gather of normalised partial points + EC add" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_bucket_accum<Fq>", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                      "kernel_ms": round(kern_ms, 4), "launches": launches,

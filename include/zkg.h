@@ -124,6 +124,12 @@ int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
                    uint64_t out_jac[12], void *stream);
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
                    uint64_t out_jac[24], void *stream);
+/* Window-sharded variant for multi-GPU runs where every GPU holds every base: the partial
+ * sum over the Pippenger windows first_window, first_window + window_stride, ... only, each
+ * already weighted by 2^(c w) — the partials of ranks g = 0..G-1 (first_window = g,
+ * window_stride = G) add up to zkg_msm_g1_dev's result (zkg_g1_sum).                      */
+int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
+                           unsigned first_window, unsigned window_stride, uint64_t out_jac[12], void *stream);
 /* Sum of `count` normalised-jac G1 (G2) points held in HOST memory: the combine step after
  * the per-GPU partial MSMs have been all-gathered (RCCL has no elliptic-curve reduce op). */
 int zkg_g1_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[12]);

@@ -133,3 +133,20 @@ def test_size_limits_are_refused_not_truncated(zkg):
         zkg.ntt_dev(d.data_ptr(), 29)
     # the largest windows-per-point product that is accepted is exercised by bench.py at 2^20..2^23; here: 2^24 entries per window
     # would need 1.6 GB of bases, so the positive side of the limit is covered by test_msm_full_size_properties
+
+
+@pytest.mark.parametrize("world", [2, 3, 8, 20])
+def test_window_sharded_partials_add_up(zkg, oracle, world):
+    """the multi-GPU variant in which rank g owns the Pippenger windows g, g + G, ...: the G partials (each weighted by its windows'
+    2^(c w)) sum to the plain MSM, for window counts that divide, do not divide, and are smaller than G"""
+    n = 5000
+    d_b, bases, _ = dev_bases_g1(zkg, n, 77)
+    sc = random_fr_canonical(n, 78)
+    import torch
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    full = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n)
+    parts = np.stack([zkg.msm_g1_windows_dev(d_b.data_ptr(), d_sc.data_ptr(), n, g, world) for g in range(world)])
+    assert np.array_equal(zkg.g1_sum(parts), full)
+    assert np.array_equal(full, oracle.msm_g1(bases, sc))
+    # the default entry point is unaffected by a previous subset call
+    assert np.array_equal(zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n), full)

@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libzkg.so")
 
 DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_evaluation_domain_size", "zkg_ntt_domain", "zkg_ntt_domain_dev", "zkg_msm_g1", "zkg_msm_g2",
-    "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
+    "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_msm_g1_windows_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
     "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
@@ -149,6 +149,14 @@ def msm_g2(bases, scalars):
 def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0):
     out = np.zeros(12, np.uint64)
     _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), int(scalars_mont), _p(out), _vp(stream)), "zkg_msm_g1_dev")
+    return out
+
+
+def msm_g1_windows_dev(d_bases, d_scalars, n, first_window, window_stride, scalars_mont=False, stream=0):
+    """partial MSM over the Pippenger windows first_window, first_window + window_stride, ... (window-sharded multi-GPU variant)"""
+    out = np.zeros(12, np.uint64)
+    _check(lib().zkg_msm_g1_windows_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), int(scalars_mont), C.c_uint(first_window), C.c_uint(window_stride),
+                                        _p(out), _vp(stream)), "zkg_msm_g1_windows_dev")
     return out
 
 

@@ -247,6 +247,15 @@ int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
     store_norm(out_jac, r);
     return ZKG_OK;
 }
+int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, unsigned first_window, unsigned window_stride,
+                           uint64_t out_jac[12], void *stream) {
+    REQUIRE_INIT();
+    if (!window_stride) { set_error("zkg_msm_g1_windows_dev: window_stride must be positive"); return ZKG_ERROR; }
+    G1 r; const G1Affine *b = (const G1Affine *)d_bases;
+    if (msm_shared(&b, 1, nullptr, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, nullptr, (hipStream_t)stream, first_window, window_stride)) return ZKG_ERROR;
+    store_norm(out_jac, r);
+    return ZKG_OK;
+}
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[24], void *stream) {
     REQUIRE_INIT();
     G2 r;

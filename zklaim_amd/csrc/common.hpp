@@ -93,6 +93,7 @@ int ntt_configure();
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
 MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);
 hipStream_t msm_job_stream(MsmJob *j);
+void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws);   // the job computes sum over windows w0, w0+ws, ... of 2^(cw) V_w only
 void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_destroy(MsmJob *j);
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);
@@ -103,7 +104,7 @@ int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool sc
 int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G2 *out, hipStream_t s);
 // one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s);
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0 = 0, uint32_t ws = 1);   // w0, ws: window subset (see MsmGeom)
 int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s);
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s);
 void msm_release_all();

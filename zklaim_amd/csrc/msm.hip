@@ -53,7 +53,9 @@ static constexpr int HEAVY_PART_BLOCKS = 1024, HEAVY_MERGE_BLOCKS = 256;
 static constexpr int SORT_THREADS = 1024;
 static constexpr int SCAN_ITEMS = 4;         // per thread in the block scan
 
-struct MsmGeom { uint32_t c, W, B; };        // window bits, windows, buckets per window (2^(c-1))
+// window bits, windows handled by this launch, buckets per window (2^(c-1)); the launch owns windows w0, w0 + ws, ... of the Wt
+// windows of the scalar (w0 = 0, ws = 1: all of them; a window-sharded multi-GPU run gives rank g the set w0 = g, ws = G)
+struct MsmGeom { uint32_t c, W, B, Wt, w0, ws; };
 struct HeavyItem { uint32_t start, end; };   // a part: range of the sorted index list
 struct HeavyBucket { uint32_t gb, first_item, nparts; };
 
@@ -61,7 +63,7 @@ struct HeavyBucket { uint32_t gb, first_item, nparts; };
 // bucket, so it needs W * 2^(c-1) >> 64 K buckets to fill the chip, and that outweighs the extra bucket-reduction work down to
 // 2^15 points: c = 16 there, 12 below, and small windows only for tiny inputs.  `window_hint` (the prover's witness
 // multi-exponentiations, whose scalars are mostly 0/1 so that the bucket reduction dominates) overrides the rule.
-static MsmGeom pick_geom(size_t n, int window_hint) {
+static MsmGeom pick_geom(size_t n, int window_hint, uint32_t w0 = 0, uint32_t ws = 1) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c = lg >= 15 ? 16 : lg >= 11 ? 12 : lg + 1;
     if (c < 4) c = 4;
@@ -69,7 +71,8 @@ static MsmGeom pick_geom(size_t n, int window_hint) {
     static const char *force = getenv("ZKG_MSM_C");                          // tuning aid
     if (force && atoi(force) >= 2) c = atoi(force);
     if (c > MAX_C) c = MAX_C;
-    MsmGeom g; g.c = c; g.W = (SCALAR_BITS + c - 1) / c; g.B = 1u << (c - 1);
+    MsmGeom g; g.c = c; g.Wt = (SCALAR_BITS + c - 1) / c; g.B = 1u << (c - 1);
+    g.w0 = w0; g.ws = ws ? ws : 1; g.W = w0 < g.Wt ? (g.Wt - w0 + g.ws - 1) / g.ws : 0;
     return g;
 }
 
@@ -92,11 +95,11 @@ __global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, size_t 
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
     if (mont) f = f.from_mont();
     uint32_t carry = 0;
-    for (uint32_t w = 0; w < g.W; ++w) {
+    for (uint32_t w = 0, own = g.w0, slot = 0; w < g.Wt; ++w) {                 // the carry chain runs over every window; owned ones are stored
         uint32_t raw = bits_at(f.v, w * g.c, g.c) + carry, code = 0;
         if (raw > g.B) { uint32_t d = (1u << g.c) - raw; carry = 1; if (d) code = (d << 1) | 1u; }
         else { carry = 0; if (raw) code = raw << 1; }
-        digits[(size_t)w * n + i] = code;
+        if (w == own) { digits[(size_t)slot * n + i] = code; ++slot; own += g.ws; }
     }
 }
 
@@ -393,6 +396,8 @@ struct MsmJob {
     MsmSlot slot[3]; int nslots = 0;
     MsmGeom g{}; size_t n = 0; int red_l_log = RED_L_LOG_SMALL;
     int window_hint = 0;               // 0: pick_geom's rule
+    uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
+    int empty_g1 = 0; bool empty_g2 = false;
     std::mutex mu;
 };
 
@@ -450,11 +455,13 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
     });
+    // sum_j 2^(c (w0 + j ws)) V_j: Horner with c*ws doublings per owned window, then the shift of the lowest one
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int w = (int)g.W - 1; w >= 0; --w) {
-        if (!acc.is_inf()) for (uint32_t i = 0; i < g.c; ++i) acc = acc.dbl();
+        if (!acc.is_inf()) for (uint32_t i = 0; i < g.c * g.ws; ++i) acc = acc.dbl();
         acc.add(V[w]);
     }
+    if (!acc.is_inf()) for (uint32_t i = 0; i < g.c * g.w0; ++i) acc = acc.dbl();
     return acc;
 }
 
@@ -498,6 +505,7 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     return j;
 }
 void msm_job_set_window(MsmJob *j, int c) { if (j) j->window_hint = c; }
+void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws) { if (j) { j->w0 = w0; j->ws = ws ? ws : 1; } }
 hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
 void msm_job_destroy(MsmJob *j) {
     if (!j) return;
@@ -515,7 +523,9 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
-    job->g = pick_geom(n, job->window_hint); job->n = n;
+    job->g = pick_geom(n, job->window_hint, job->w0, job->ws); job->n = n;
+    job->nslots = 0; job->empty_g1 = 0; job->empty_g2 = false;
+    if (job->g.W == 0) { job->empty_g1 = n_g1; job->empty_g2 = d_g2_bases != nullptr; return ZKG_OK; }     // this rank owns no window: its partial is the identity
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
     job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
     if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
@@ -535,6 +545,11 @@ int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, con
 // wait for the job's stream and finish on the host; outputs in launch order (G1 sets, then the G2 set)
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
     ZK_HIP(hipStreamSynchronize(job->stream));
+    if (job->empty_g1 || job->empty_g2) {
+        for (int i = 0; i < job->empty_g1; ++i) out_g1[i] = G1::inf();
+        if (job->empty_g2) *out_g2 = G2::inf();
+        return ZKG_OK;
+    }
     int k = 0;
     for (int i = 0; i < job->nslots; ++i) {
         if (job->slot[i].g2) *out_g2 = host_combine<Fq2>(job, job->slot[i]);
@@ -545,9 +560,9 @@ int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
 
 
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s) {
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0, uint32_t ws) {
     std::lock_guard<std::mutex> lk(g_default_job.mu);
-    g_default_job.stream = s;
+    g_default_job.stream = s; g_default_job.w0 = w0; g_default_job.ws = ws ? ws : 1;
     if (msm_job_launch(&g_default_job, d_g1_bases, n_g1, d_g2_bases, d_scalars, n, scalars_mont)) return ZKG_ERROR;
     return msm_job_finish(&g_default_job, out_g1, out_g2);
 }

@@ -19,6 +19,12 @@ def shard_bounds(n_total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def window_shard(world, rank):
+    """the window-sharded variant (every GPU holds every base): rank g owns the Pippenger windows g, g + G, g + 2G, ...
+    -> (first_window, window_stride) for zkg_msm_g1_windows_dev"""
+    return rank, world
+
+
 class _Exchange:
     """Persistent buffers of the partial-point exchange (one per (group, device, point size)): a pinned host staging pair and
     a device pair for the RCCL path, plain CPU tensors for gloo.  One all_gather_into_tensor per call, no allocation."""
