@@ -80,3 +80,36 @@ def test_payload_counts(oracle):
         assert ck.is_satisfied()
         assert ck.r1cs.num_inputs == -(-1280 * k // 253)
         assert np.array_equal(zkg.zklaim_input_map(ctx), ck.witness()[: ck.r1cs.num_inputs])
+
+
+def test_parallel_sub_circuits_equal_the_serial_pass():
+    """payload sub-circuits built on the host pool through views (variables, witness, constraints appended in payload order)
+    give byte-identical CSR matrices and witness to the single-threaded pass"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import zklaim_amd as zkg
+keep = []
+pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i) for i in range(3)]
+ck = zkg.ZklaimCircuit(zkg.make_ctx(pls, keep))
+h = hashlib.sha256()
+for m in ck.csr():
+    for a in m:
+        h.update(np.ascontiguousarray(a).tobytes())
+h.update(np.ascontiguousarray(ck.witness()).tobytes())
+wo = zkg.ZklaimCircuit(zkg.make_ctx(pls, keep), witness_only=True)
+h.update(np.ascontiguousarray(wo.witness()).tobytes())
+print(h.hexdigest(), ck.r1cs.num_constraints, ck.r1cs.num_variables)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for serial in (False, True):
+        env = dict(os.environ)
+        env.pop("ZKG_SERIAL_CIRCUIT", None)
+        if serial:
+            env["ZKG_SERIAL_CIRCUIT"] = "1"
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and outs[0].split()[1] == str(3 * 27573 + 2), outs

@@ -27,19 +27,30 @@ struct LC {                              // sparse linear combination sum coeff_
     bool is_constant() const { for (auto &e : t) if (e.first != 0) return false; return true; }
 };
 
-struct Constraint { LC a, b, c; };
+// a recorded constraint: three runs of terms in the builder's arena (one allocation for the whole system instead of three
+// small vectors per constraint: building is faster and freeing half a million constraints is two deallocations)
+struct Span { uint32_t off, len; };
+struct Constraint { Span a, b, c; };
 
 struct Builder {
     std::vector<Fr> val;                 // val[0] == 1
     std::vector<uint8_t> nz;             // nz[v] = (val[v] != 0): what the boolean gadgets read on the witness path
     std::vector<Constraint> cons;
+    std::vector<std::pair<Var, Fr>> arena;
     uint32_t num_inputs = 0;
     bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
     // A view allocates from a pre-sized range [cursor, cursor_end) of its root's storage and reads / writes values there: the
     // per-payload sub-circuits of a witness-only pass are independent and run on separate threads through views.
     Builder *root = nullptr; uint32_t cursor = 0, cursor_end = 0;
     Builder() { val.push_back(Fr::one()); nz.push_back(1); }
-    static Builder view_of(Builder &r, uint32_t begin, uint32_t end) { Builder v; v.root = &r; v.cursor = begin; v.cursor_end = end; v.recording = false; return v; }
+    static Builder view_of(Builder &r, uint32_t begin, uint32_t end) { Builder v; v.root = &r; v.cursor = begin; v.cursor_end = end; v.recording = r.recording; return v; }
+    // append the constraints a view recorded (views keep their own cons / arena; merged in payload order the result is the serial one)
+    void absorb(const Builder &v) {
+        const uint32_t base = (uint32_t)arena.size();
+        arena.insert(arena.end(), v.arena.begin(), v.arena.end());
+        cons.reserve(cons.size() + v.cons.size());
+        for (Constraint c : v.cons) { c.a.off += base; c.b.off += base; c.c.off += base; cons.push_back(c); }
+    }
     void reserve(size_t nvars) { val.reserve(nvars + 1); nz.reserve(nvars + 1); }
     uint32_t extend(size_t count) { uint32_t first = (uint32_t)val.size(); val.resize(val.size() + count, Fr::zero()); nz.resize(nz.size() + count, 0); return first; }
     Var alloc() {
@@ -52,16 +63,24 @@ struct Builder {
     std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
     void set_input_sizes(uint32_t n) { num_inputs = n; }
     uint32_t num_variables() const { return (uint32_t)val.size() - 1; }
-    void enforce(const LC &a, const LC &b, const LC &c) { if (recording) cons.push_back({a, b, c}); }
+    Span put(const LC &l) { Span sp{(uint32_t)arena.size(), (uint32_t)l.t.size()}; arena.insert(arena.end(), l.t.begin(), l.t.end()); return sp; }
+    void enforce(const LC &a, const LC &b, const LC &c) { if (recording) { Span sa = put(a), sb = put(b), sc = put(c); cons.push_back({sa, sb, sc}); } }
     void enforce_boolean(Var v) { if (recording) enforce(LC(v), LC::constant(1) - LC(v), LC()); }          // v (1 - v) = 0
     Fr eval(const LC &l) const { Fr s = Fr::zero(); for (auto &e : l.t) s += e.second * val[e.first]; return s; }
+    Fr eval(const Span &sp) const { Fr s = Fr::zero(); for (uint32_t i = sp.off; i < sp.off + sp.len; ++i) s += arena[i].second * val[arena[i].first]; return s; }
     bool is_satisfied() const { for (auto &c : cons) if (eval(c.a) * eval(c.b) != eval(c.c)) return false; return true; }
     size_t first_unsatisfied() const { for (size_t i = 0; i < cons.size(); ++i) if (eval(cons[i].a) * eval(cons[i].b) != eval(cons[i].c)) return i; return (size_t)-1; }
 
     // CSR export (terms on the same variable merged, zero coefficients dropped): the zkg_r1cs layout
     struct Csr { std::vector<uint32_t> rowptr, col; std::vector<uint64_t> val; };
-    static void push_row(Csr &m, const LC &l) {
-        std::vector<std::pair<Var, Fr>> s = l.t;
+    void push_row(Csr &m, const Span &sp, std::vector<std::pair<Var, Fr>> &s) const {      // s: scratch, reused from row to row
+        if (sp.len == 1) {                                                                  // the common row: one term
+            const auto &e = arena[sp.off];
+            if (!e.second.is_zero()) { m.col.push_back(e.first); uint64_t l4[4]; memcpy(l4, e.second.v, 32); m.val.insert(m.val.end(), l4, l4 + 4); }
+            m.rowptr.push_back((uint32_t)m.col.size());
+            return;
+        }
+        s.assign(arena.begin() + sp.off, arena.begin() + sp.off + sp.len);
         std::stable_sort(s.begin(), s.end(), [](const std::pair<Var, Fr> &x, const std::pair<Var, Fr> &y) { return x.first < y.first; });
         for (size_t i = 0; i < s.size();) {
             Fr acc = Fr::zero(); size_t j = i;
@@ -71,10 +90,16 @@ struct Builder {
         }
         m.rowptr.push_back((uint32_t)m.col.size());
     }
-    void export_csr(Csr &A, Csr &B, Csr &C) const {
-        for (Csr *m : {&A, &B, &C}) { m->rowptr.assign(1, 0); m->col.clear(); m->val.clear(); }
-        for (auto &c : cons) { push_row(A, c.a); push_row(B, c.b); push_row(C, c.c); }
+    void export_matrix(int which, Csr &m) const {                                           // 0 = A, 1 = B, 2 = C; independent of each other
+        m.rowptr.assign(1, 0); m.col.clear(); m.val.clear();
+        m.rowptr.reserve(cons.size() + 1);
+        size_t terms = 0;
+        for (auto &c : cons) terms += (which == 0 ? c.a : which == 1 ? c.b : c.c).len;
+        m.col.reserve(terms); m.val.reserve(4 * terms);
+        std::vector<std::pair<Var, Fr>> scratch;
+        for (auto &c : cons) push_row(m, which == 0 ? c.a : which == 1 ? c.b : c.c, scratch);
     }
+    void export_csr(Csr &A, Csr &B, Csr &C) const { export_matrix(0, A); export_matrix(1, B); export_matrix(2, C); }
 };
 
 }}  // namespace zk::circuit

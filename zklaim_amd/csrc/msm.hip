@@ -584,7 +584,8 @@ __global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, cons
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int b = 0; b < 254; ++b)
         if ((k[b >> 5] >> (b & 31)) & 1u) acc.madd(table[b]);
-    out[i] = acc.to_affine().normalized();
+    XYZZ<F> fin = acc;                     // to_affine() is out of line: only this copy has its address taken, the loop's accumulator stays in registers
+    out[i] = fin.to_affine().normalized();
 }
 
 template <class F>

@@ -243,12 +243,22 @@ bool domain_shape_of(size_t m, DomainShape &d) { return evaluation_domain_shape(
 //   basic:  u_i = Z(t) w^i / (m (t - w^i)),                                   Z(t) = t^m - 1
 //   step:   u_i = Zb(t) wb^i (t^small - omega^small) / (big (t - wb^i)(wb^(i small) - omega^small))   for i < big
 //           u_(big+i) = (t^big - 1)/(omega^big - 1) * Zs(t') ws^i / (small (t' - ws^i)),  t' = t / omega
-static int batch_invert(std::vector<Fr> &den) {
-    std::vector<Fr> pre(den.size());
+static int batch_invert_range(Fr *den, size_t n) {
+    std::vector<Fr> pre(n);
     Fr run = Fr::one();
-    for (size_t i = 0; i < den.size(); ++i) { if (den[i].is_zero()) return ZKG_ERROR; pre[i] = run; run = run * den[i]; }
+    for (size_t i = 0; i < n; ++i) { if (den[i].is_zero()) return ZKG_ERROR; pre[i] = run; run = run * den[i]; }
     Fr inv = run.inverse();
-    for (size_t i = den.size(); i-- > 0;) { Fr di = inv * pre[i]; inv = inv * den[i]; den[i] = di; }
+    for (size_t i = n; i-- > 0;) { Fr di = inv * pre[i]; inv = inv * den[i]; den[i] = di; }
+    return ZKG_OK;
+}
+// Montgomery's trick, one inversion per chunk, chunks on the host pool
+static int batch_invert(std::vector<Fr> &den) {
+    const size_t n = den.size();
+    const int chunks = (int)std::min<size_t>(64, (n + 8191) / 8192);
+    if (chunks <= 1) return batch_invert_range(den.data(), n);
+    std::vector<int> rc(chunks, 0);
+    host_parallel_for(chunks, [&](int c) { size_t lo = n * (size_t)c / chunks, hi = n * (size_t)(c + 1) / chunks; rc[c] = batch_invert_range(den.data() + lo, hi - lo); });
+    for (int r : rc) if (r) return ZKG_ERROR;
     return ZKG_OK;
 }
 int domain_lagrange(const DomainShape &d, const Fr &t, std::vector<Fr> &u, Fr &Zt) {

@@ -11,6 +11,9 @@
 // step_radix2 domain for some sizes; this build always uses basic radix-2 domains).
 // Verifier: host pairing (host/pairing.hpp); the public input is folded into gamma_ABC with host scalar multiplications.
 #include "common.hpp"
+#include <algorithm>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include "../../include/zkg.h"
 #include "host/serialize.hpp"
@@ -25,6 +28,7 @@ struct zkg_keypair {
     // the (possibly swapped) constraint system stored in the pk
     std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
     uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0; bool swapped = false;
+    std::vector<uint8_t> pk_blob; std::mutex blob_mu;            // serialised once, on first request
     G1Affine alpha_g1, beta_g1, delta_g1; G2Affine beta_g2, delta_g2, gamma_g2;
     std::vector<G1Affine> A_query, B_g1, H_query, L_query, IC;
     std::vector<G2Affine> B_g2;
@@ -127,9 +131,10 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
     for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
     std::vector<Fr> *dst[3] = {&At, &Bt, &Ct};
-    for (int k = 0; k < 3; ++k)
+    host_parallel_for(3, [&](int k) {                                       // the three matrices accumulate into separate vectors
         for (size_t i = 0; i < C; ++i)
             for (uint32_t e = kp->rp[k][i]; e < kp->rp[k][i + 1]; ++e) { Fr c; memcpy(c.v, &kp->val[k][4 * (size_t)e], 32); (*dst[k])[kp->col[k][e]] += u[i] * c; }
+    });
     Fr dinv = delta.inverse(), ginv = gamma.inverse();
     std::vector<Fr> Hs(m - 1), Ls(n - l), ICs(l + 1);
     { Fr ti = Fr::one(), zd = Zt * dinv; for (size_t i = 0; i + 1 < m; ++i) { Hs[i] = ti * zd; ti = ti * t; } }
@@ -168,27 +173,46 @@ void zkg_keypair_free(zkg_keypair *kp) { delete kp; }
 const zkg_pk *zkg_keypair_pk(const zkg_keypair *kp) { return kp ? &kp->pk_view : nullptr; }
 int zkg_keypair_swapped(const zkg_keypair *kp) { return kp && kp->swapped ? 1 : 0; }
 
-// operator<<(r1cs_gg_ppzksnark_proving_key), layout in codec.hip
-size_t zkg_keypair_pk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
-    if (!kp) return 0;
+// operator<<(r1cs_gg_ppzksnark_proving_key), layout in codec.hip.  Built once per keypair (callers ask for the size first, then for
+// the bytes); the fixed-size point records — 2.2 M of them at 20 payloads — are serialised on the host pool.
+static void build_pk_blob(const zkg_keypair *kp, std::vector<uint8_t> &buf) {
     ser::Writer w;
-    w.buf.reserve((kp->A_query.size() + kp->H_query.size() + kp->L_query.size()) * 34 + kp->B_g2.size() * 108 + (kp->col[0].size() + kp->col[1].size() + kp->col[2].size()) * 40 + (size_t)kp->C * 8 + 4096);
-    w.g1(kp->alpha_g1); w.g1(kp->beta_g1); w.g2(kp->beta_g2); w.g1(kp->delta_g1); w.g2(kp->delta_g2);
-    w.dec(kp->A_query.size()); for (auto &p : kp->A_query) w.g1(p);
     std::vector<size_t> idx;
     for (size_t i = 0; i < kp->B_g2.size(); ++i) if (!kp->B_g2[i].is_inf() || !kp->B_g1[i].is_inf()) idx.push_back(i);
+    const size_t nterms = kp->col[0].size() + kp->col[1].size() + kp->col[2].size();
+    w.buf.reserve((kp->A_query.size() + kp->H_query.size() + kp->L_query.size()) * 34 + idx.size() * 108 + nterms * 40 + (size_t)kp->C * 8 + 4096);
+    // a run of fixed-size records: reserve the bytes, fill them in parallel
+    auto records = [&](size_t count, size_t rec, const std::function<void(size_t, uint8_t *)> &put) {
+        const size_t at = w.buf.size();
+        w.buf.resize(at + count * rec);
+        uint8_t *base = w.buf.data() + at;
+        const int chunks = (int)std::min<size_t>(64, (count + 4095) / 4096);
+        host_parallel_for(chunks, [&](int c) {
+            size_t lo = count * (size_t)c / chunks, hi = count * (size_t)(c + 1) / chunks;
+            for (size_t i = lo; i < hi; ++i) put(i, base + i * rec);
+        });
+    };
+    w.g1(kp->alpha_g1); w.g1(kp->beta_g1); w.g2(kp->beta_g2); w.g1(kp->delta_g1); w.g2(kp->delta_g2);
+    w.dec(kp->A_query.size()); records(kp->A_query.size(), 34, [&](size_t i, uint8_t *o) { ser::put_g1(o, kp->A_query[i]); });
     w.dec(kp->B_g2.size()); w.dec(idx.size()); for (size_t i : idx) w.dec(i);
-    w.dec(idx.size()); for (size_t i : idx) { w.g2(kp->B_g2[i]); w.g1(kp->B_g1[i]); }
-    w.dec(kp->H_query.size()); for (auto &p : kp->H_query) w.g1(p);
-    w.dec(kp->L_query.size()); for (auto &p : kp->L_query) w.g1(p);
+    w.dec(idx.size()); records(idx.size(), 100, [&](size_t j, uint8_t *o) { ser::put_g2(o, kp->B_g2[idx[j]]); ser::put_g1(o + 66, kp->B_g1[idx[j]]); });
+    w.dec(kp->H_query.size()); records(kp->H_query.size(), 34, [&](size_t i, uint8_t *o) { ser::put_g1(o, kp->H_query[i]); });
+    w.dec(kp->L_query.size()); records(kp->L_query.size(), 34, [&](size_t i, uint8_t *o) { ser::put_g1(o, kp->L_query[i]); });
     w.dec(kp->l); w.dec(kp->n - kp->l); w.dec(kp->C);
     for (uint32_t c = 0; c < kp->C; ++c)
         for (int k = 0; k < 3; ++k) {
             w.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
             for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { w.dec(kp->col[k][e]); w.raw(&kp->val[k][4 * (size_t)e], 32); }
         }
-    if (out && cap >= w.buf.size()) memcpy(out, w.buf.data(), w.buf.size());
-    return w.buf.size();
+    buf.swap(w.buf);
+}
+size_t zkg_keypair_pk_blob(const zkg_keypair *kp_, uint8_t *out, size_t cap) {
+    zkg_keypair *kp = const_cast<zkg_keypair *>(kp_);
+    if (!kp) return 0;
+    std::lock_guard<std::mutex> lk(kp->blob_mu);
+    if (kp->pk_blob.empty()) build_pk_blob(kp, kp->pk_blob);
+    if (out && cap >= kp->pk_blob.size()) memcpy(out, kp->pk_blob.data(), kp->pk_blob.size());
+    return kp->pk_blob.size();
 }
 
 // operator<<(r1cs_gg_ppzksnark_verification_key): alpha_g1_beta_g2 (GT, 384 B) | gamma_g2 | delta_g2 | gamma_ABC_g1 as an

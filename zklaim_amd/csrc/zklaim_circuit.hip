@@ -176,25 +176,34 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         block[512 - 9] = Bit::one(); block[512 - 8] = Bit::one();              // length 384 = 0x0180, big-endian in the last 64 bits
         sha256_compress_from_iv(pb, block, h_bits[i]);
     };
-    if (witness_only && k > 1) {
-        // Witness only: the k sub-circuits allocate the same number of variables each and touch disjoint ranges, so payload 0 runs
-        // here (and measures that number) and payloads 1..k-1 run on the host thread pool through views of the pre-sized storage.
+    if (k > 1 && !getenv("ZKG_SERIAL_CIRCUIT")) {                                  // (the env switch keeps the serial pass available to the tests)
+        // The k sub-circuits allocate the same number of variables each and touch disjoint ranges, so payload 0 runs here (and measures
+        // that number) and payloads 1..k-1 run on the host thread pool through views of the pre-sized storage; constraints recorded by
+        // the views are appended in payload order, which makes the system identical to the one a serial pass records.
         const uint32_t before = pb.num_variables();
+        const size_t cons_before = pb.cons.size(), terms_before = pb.arena.size();
         payload_gadgets(pb, 0);
         const uint32_t per = pb.num_variables() - before;
+        const size_t cons_per = pb.cons.size() - cons_before, terms_per = pb.arena.size() - terms_before;
+        if (pb.recording) { pb.cons.reserve(pb.cons.size() + cons_per * (k - 1)); pb.arena.reserve(pb.arena.size() + terms_per * (k - 1)); }
         const uint32_t first = pb.extend((size_t)per * (k - 1));
         std::vector<char> bad(k, 0);
+        std::vector<Builder> views(k - 1);
         host_parallel_for((int)k - 1, [&](int t) {
-            Builder v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
+            Builder &v = views[t];
+            v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
+            if (v.recording) { v.cons.reserve(cons_per); v.arena.reserve(terms_per); }
             payload_gadgets(v, (size_t)t + 1);
             bad[t + 1] = v.cursor != v.cursor_end;
         });
         for (char b : bad) if (b) { delete ck; set_error("zklaim circuit: payload sub-circuits differ in size"); return nullptr; }
+        if (pb.recording) for (const Builder &v : views) pb.absorb(v);
     } else {
         for (size_t i = 0; i < k; ++i) payload_gadgets(pb, i);
     }
     lap("payload sub-circuits");
-    if (pb.recording) pb.export_csr(ck->A, ck->B, ck->C);
+    if (pb.recording) { Builder::Csr *ms[3] = {&ck->A, &ck->B, &ck->C}; host_parallel_for(3, [&](int m) { pb.export_matrix(m, *ms[m]); }); }
+    lap("CSR exported");
     ck->has_witness = with_witness;             // the witness is pb.val[1..] itself: Fr is the ABI's 4 x u64 Montgomery element
     return ck;
 }
