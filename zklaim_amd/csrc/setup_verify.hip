@@ -84,11 +84,6 @@ G2Affine g2_generator() {
             {limbs({0x886be9f6u, 0x619dfa9du, 0xf59e9b78u, 0xfe7fd297u, 0x231b7dfeu, 0xff9e1a62u, 0xae9e4206u, 0x28fd7eebu}),
              limbs({0xc71856eeu, 0x64095b56u, 0x327d3cbbu, 0xdc57f922u, 0x33351076u, 0x55f935beu, 0x93fd6482u, 0x0da4a0e6u})}};
 }
-Fr fr_root_of_unity_2p28() {
-    Fr r; const uint32_t l[8] = {0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u, 0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u};
-    for (int i = 0; i < 8; ++i) r.v[i] = l[i];
-    return r;
-}
 void fr_limbs(const Fr &x, uint32_t out[8]) { Fr c = x.from_mont(); memcpy(out, c.v, 32); }
 
 }  // namespace
