@@ -122,3 +122,4 @@ def test_prove_real_zklaim_circuit(zkg, oracle):
     rc, _ = crs.prove(wbad, rs[0], rs[1])
     assert rc == 1
     crs.free()
+

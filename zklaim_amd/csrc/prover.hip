@@ -26,6 +26,24 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 
 }  // namespace zk
 
+// Everything one proof in flight needs on top of the shared key: its [1 | w], the three evaluation vectors, the transform
+// scratch, a stream for the mat-vec / NTT pipeline, five MSM jobs (stream + workspace + pinned landing zone each) and the
+// events that order them.  One per key: keeping two proofs in flight (the host tail of proof i under the GPU work of proof
+// i+1) was built and measured — 3.1 ms per proof against 2.7 ms one at a time at 8 payloads, 2.0 against 1.6 at one — because
+// one proof's five concurrent MSMs already fill the chip, and ten of them contend.
+struct ProverSlot {
+    zk::DevBuf z, aABC, flag;                   // [1 | w] and aA | aB | aC back to back (batched NTTs)
+    zk::DevBuf ntt_scratch;                     // inter-pass scratch, 3 m elements
+    hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
+    zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;
+    hipEvent_t ev[20]; bool ev_ok = false, ready = false;
+    float stage_ms[8] = {0};
+    // the proof in flight between prove_enqueue and prove_finish
+    uint32_t *flag_host = nullptr;              // pinned: lands the satisfiability flag
+    bool check = false; zk::Fr r, s;
+    std::chrono::steady_clock::time_point t0;
+};
+
 struct zkg_crs {
     uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0;
     zk::DevCsr A, B, Cm;
@@ -34,14 +52,10 @@ struct zkg_crs {
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
     zk::StepDomain *sdom = nullptr;             // ... or step_radix2_domain (m = 2^(log_m-1) + 2^b); exactly one is set
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
-    zk::DevBuf z, aABC, flag;                   // [1 | w] and the three evaluation vectors aA | aB | aC back to back (batched NTTs)
     zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
-    zk::DevBuf ntt_scratch;                     // this CRS's own inter-pass scratch, 3 m elements (the batched transforms)
-    hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
-    zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;   // concurrent MSMs, one stream + workspace each
+    ProverSlot slot[1];
     float stage_ms[8] = {0};
-    hipEvent_t ev[20]; bool ev_ok = false;
     std::mutex mu;
 };
 
@@ -147,13 +161,14 @@ static size_t ser_g2(uint8_t *out, const G2 &p) {
     return 66;
 }
 
-static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint32_t *flag_out, hipStream_t s) {
+static int compute_h(zkg_crs *crs, ProverSlot &S, const uint64_t *witness, bool want_flag) {
+    hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
-    Fr *z = crs->z.as<Fr>(), *aA = crs->aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
+    Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
     if (crs->n) ZK_HIP(hipMemcpyAsync(z + 1, witness, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
-    ZK_HIP(hipMemsetAsync(crs->flag.p, 0, 4, s));
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[0], s);                      // z = [1 | w] is resident from here on
+    ZK_HIP(hipMemsetAsync(S.flag.p, 0, 4, s));
+    if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident from here on
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
@@ -165,11 +180,11 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
                            crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                            crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(), z, aA, aB, aC);
     if (want_flag) {
-        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, crs->flag.as<uint32_t>());
-        ZK_HIP(hipMemcpyAsync(flag_out, crs->flag.p, 4, hipMemcpyDeviceToHost, s));
+        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, S.flag.as<uint32_t>());
+        ZK_HIP(hipMemcpyAsync(flag_out, S.flag.p, 4, hipMemcpyDeviceToHost, s));
     }
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[1], s);
-    Fr *scr = crs->ntt_scratch.as<Fr>();
+    if (S.ev_ok) (void)hipEventRecord(S.ev[1], s);
+    Fr *scr = S.ntt_scratch.as<Fr>();
     const unsigned grid_m = (unsigned)((m + 255) / 256);
     if (crs->dom) {
         // iFFT then cosetFFT of aA, aB, aC as ONE batch of three (a single 2^18 transform fills half the chip; three fill it):
@@ -188,9 +203,50 @@ static int compute_h(zkg_crs *crs, const uint64_t *witness, bool want_flag, uint
                            (uint32_t)(sd->shape.big / sd->shape.small - 1), sd->zinv_small);
         if (step_ntt_run(sd, aA, true, true, s, scr, 1, m)) return ZKG_ERROR;                      // icosetFFT
     }
-    if (crs->ev_ok) (void)hipEventRecord(crs->ev[2], s);
+    if (S.ev_ok) (void)hipEventRecord(S.ev[2], s);
     if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
+}
+
+static int slot_create(zkg_crs *crs, ProverSlot &S) {
+    if (S.ready) return ZKG_OK;
+    const size_t n = crs->n, m = crs->m;
+    bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * 32) == 0 &&
+              hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
+    if (ok) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
+        ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
+        S.job_a = msm_job_create(nullptr, true); S.job_b1 = msm_job_create(nullptr, true); S.job_b2 = msm_job_create(nullptr, true);
+        S.job_h = msm_job_create(nullptr, true, true); S.job_l = msm_job_create(nullptr, true);
+        ok = ok && S.job_a && S.job_b1 && S.job_b2 && S.job_h && S.job_l;
+        if (ok) {
+            // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
+            // mostly 0/1 scalars (one heavy bucket) and few full-size ones, so their time is the bucket reduction's: small windows.
+            const char *cw = getenv("ZKG_MSM_C_W"), *c2 = getenv("ZKG_MSM_C_G2");           // tuning aids
+            int w1 = cw ? atoi(cw) : 12, w2 = c2 ? atoi(c2) : w1;
+            for (MsmJob *j : {S.job_a, S.job_b1, S.job_l}) msm_job_set_window(j, w1);
+            msm_job_set_window(S.job_b2, w2);
+        }
+    }
+    if (ok) {
+        S.ev_ok = true;
+        for (auto &e : S.ev) if (hipEventCreate(&e) != hipSuccess) S.ev_ok = false;
+        if (!S.ev_ok) { set_error("hipEventCreate failed"); ok = false; }
+    }
+    S.ready = ok;
+    return ok ? ZKG_OK : ZKG_ERROR;
+}
+static void slot_destroy(ProverSlot &S) {
+    for (DevBuf *b : {&S.z, &S.aABC, &S.flag, &S.ntt_scratch}) b->release();
+    msm_job_destroy(S.job_a); msm_job_destroy(S.job_b1); msm_job_destroy(S.job_b2); msm_job_destroy(S.job_h); msm_job_destroy(S.job_l);
+    S.job_a = S.job_b1 = S.job_b2 = S.job_h = S.job_l = nullptr;
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    S.stream = nullptr;
+    if (S.ev_ok) for (auto &e : S.ev) (void)hipEventDestroy(e);
+    S.ev_ok = false;
+    if (S.flag_host) (void)hipHostFree(S.flag_host);
+    S.flag_host = nullptr; S.ready = false;
 }
 
 }  // namespace zk
@@ -236,31 +292,7 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
         ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0;
     }
-    if (ok) {
-        ok = crs->z.reserve((n + 1) * 32) == 0 && crs->aABC.reserve(3 * m * 32) == 0 &&
-             crs->flag.reserve(4) == 0 && crs->ntt_scratch.reserve(3 * m * 32) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
-    }
-    if (ok) {
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
-        ok = hip_ok(hipStreamCreateWithPriority(&crs->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
-        crs->job_a = msm_job_create(nullptr, true); crs->job_b1 = msm_job_create(nullptr, true); crs->job_b2 = msm_job_create(nullptr, true);
-        crs->job_h = msm_job_create(nullptr, true, true); crs->job_l = msm_job_create(nullptr, true);
-        ok = ok && crs->job_a && crs->job_b1 && crs->job_b2 && crs->job_h && crs->job_l;
-        if (ok) {
-            // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
-            // mostly 0/1 scalars (one heavy bucket) and few full-size ones, so their time is the bucket reduction's: small windows.
-            const char *cw = getenv("ZKG_MSM_C_W"), *c2 = getenv("ZKG_MSM_C_G2");           // tuning aids
-            int w1 = cw ? atoi(cw) : 12, w2 = c2 ? atoi(c2) : w1;
-            for (MsmJob *j : {crs->job_a, crs->job_b1, crs->job_l}) msm_job_set_window(j, w1);
-            msm_job_set_window(crs->job_b2, w2);
-        }
-    }
-    if (ok) {
-        crs->ev_ok = true;
-        for (auto &e : crs->ev) if (hipEventCreate(&e) != hipSuccess) crs->ev_ok = false;
-        if (!crs->ev_ok) { set_error("hipEventCreate failed"); ok = false; }
-    }
+    ok = ok && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) && slot_create(crs, crs->slot[0]) == ZKG_OK;
     if (!ok) { zkg_crs_free(crs); return nullptr; }
     return crs;
 }
@@ -268,12 +300,9 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
-                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->z, &crs->aABC, &crs->flag,
-                      &crs->ntt_scratch, &crs->long_rows})
+                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->long_rows})
         b->release();
-    msm_job_destroy(crs->job_a); msm_job_destroy(crs->job_b1); msm_job_destroy(crs->job_b2); msm_job_destroy(crs->job_h); msm_job_destroy(crs->job_l);
-    if (crs->stream) (void)hipStreamDestroy(crs->stream);
-    if (crs->ev_ok) for (auto &e : crs->ev) (void)hipEventDestroy(e);
+    for (ProverSlot &S : crs->slot) slot_destroy(S);
     delete crs;
 }
 
@@ -281,11 +310,101 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
-    uint32_t flag = 0;
-    if (compute_h(crs, witness, false, &flag, crs->stream)) return ZKG_ERROR;
-    ZK_HIP(hipStreamSynchronize(crs->stream));
-    ZK_HIP(hipMemcpy(h_out, crs->aABC.p, crs->m * 32, hipMemcpyDeviceToHost));
+    ProverSlot &S = crs->slot[0];
+    if (compute_h(crs, S, witness, false)) return ZKG_ERROR;
+    ZK_HIP(hipStreamSynchronize(S.stream));
+    ZK_HIP(hipMemcpy(h_out, S.aABC.p, crs->m * 32, hipMemcpyDeviceToHost));
     memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
+    return ZKG_OK;
+}
+
+// ---- one proof = prove_enqueue (everything the GPU does, queued without waiting) + prove_finish (host tails, assembly, bytes)
+static const bool g_dbg_timing = getenv("ZKG_DEBUG_TIMING") != nullptr, g_serial_msm = getenv("ZKG_SERIAL_MSM") != nullptr;
+static void lap(const ProverSlot &S, const char *what) {
+    if (g_dbg_timing) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
+}
+struct MsmLaunch { MsmJob *job; const G1Affine *g1; const G2Affine *g2; const uint32_t *sc; size_t cnt; int wait_ev, ev0; };
+static void slot_launches(const zkg_crs *crs, const ProverSlot &S, MsmLaunch out[5]) {
+    const size_t n = crs->n, l = crs->l, m = crs->m;
+    const uint32_t *z = S.z.as<uint32_t>();
+    // A / B_g1 / B_g2 and L only need z (event 0); H needs the NTT pipeline (event 2).  Scalars are Montgomery Fr on device.
+    const MsmLaunch L[5] = {
+        {S.job_b2, nullptr, crs->B_g2.as<G2Affine>(), z, n + 1, 0, 3},                  // the G2 MSM is the long pole: first
+        {S.job_a, crs->A_query.as<G1Affine>(), nullptr, z, n + 1, 0, 5},
+        {S.job_b1, crs->B_g1.as<G1Affine>(), nullptr, z, n + 1, 0, 7},
+        {S.job_l, crs->L_query.as<G1Affine>(), nullptr, z + 8 * (l + 1), n - l, 0, 9},
+        {S.job_h, crs->H_query.as<G1Affine>(), nullptr, S.aABC.as<uint32_t>(), m - 1, 2, 11}};
+    for (int i = 0; i < 5; ++i) out[i] = L[i];
+}
+static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const uint64_t *witness, const uint64_t r_[4], const uint64_t s_[4], bool check) {
+    S.t0 = std::chrono::steady_clock::now();
+    S.check = check; memcpy(S.r.v, r_, 32); memcpy(S.s.v, s_, 32);
+    *S.flag_host = 0;
+    if (compute_h(crs, S, witness, check)) return ZKG_ERROR;
+    lap(S, "h pipeline enqueued");
+    MsmLaunch launches[5]; slot_launches(crs, S, launches);
+    for (const MsmLaunch &L : launches) {                                    // concurrently, each on its own stream
+        hipStream_t js = msm_job_stream(L.job);
+        ZK_HIP(hipStreamWaitEvent(js, S.ev[L.wait_ev], 0));
+        (void)hipEventRecord(S.ev[L.ev0], js);
+        if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
+        (void)hipEventRecord(S.ev[L.ev0 + 1], js);
+        if (g_serial_msm) (void)hipStreamSynchronize(js);                   // profiling aid: one multi-exponentiation at a time
+    }
+    lap(S, "msm jobs enqueued");
+    return ZKG_OK;
+}
+static void slot_drain(const zkg_crs *crs, ProverSlot &S) {                  // after an error: nothing of this slot may still be running
+    MsmLaunch launches[5]; slot_launches(crs, S, launches);
+    (void)hipStreamSynchronize(S.stream);
+    for (const MsmLaunch &L : launches) (void)hipStreamSynchronize(msm_job_stream(L.job));
+}
+static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t *proof_len) {
+    hipStream_t s = S.stream;
+    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
+    // host work that needs only the CRS and (r, s): overlaps the GPU
+    uint32_t rc[8], sc[8], rsc[8];
+    canonical_limbs(S.r, rc); canonical_limbs(S.s, sc); canonical_limbs(S.r * S.s, rsc);
+    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
+    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
+    G1 r_delta1 = delta1.mul(rc, 8), s_delta1 = delta1.mul(sc, 8), rs_delta1 = delta1.mul(rsc, 8);
+    G2 s_delta2 = delta2.mul(sc, 8);
+    lap(S, "crs-only host products");
+    if (S.check) {
+        ZK_HIP(hipStreamSynchronize(s));
+        if (*S.flag_host) {                                                  // drain the speculative MSMs, then refuse like snark.cpp:121-124
+            slot_drain(crs, S);
+            set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
+        }
+    }
+    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing.
+    //      A and B_g1 end early: s*A + r*B_1 - rs*delta (two 254-bit scalar multiplications, ~0.2 ms) is formed while H is still on
+    //      the GPU; B_g2's host tail (chunk sums and 255 G2 doublings, ~0.3 ms) runs on a helper thread.
+    auto g2_tail = std::async(std::launch::async, [&] { return msm_job_finish(S.job_b2, nullptr, &Bt2); });
+    if (msm_job_finish(S.job_a, &AB[0], nullptr) || msm_job_finish(S.job_b1, &AB[1], nullptr)) { (void)g2_tail.get(); slot_drain(crs, S); return ZKG_ERROR; }
+    G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
+    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
+    G1 gC = gA.mul(sc, 8); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
+    lap(S, "s*A + r*B1 - rs*delta");
+    if (msm_job_finish(S.job_l, &Lt, nullptr) || msm_job_finish(S.job_h, &Ht, nullptr)) { (void)g2_tail.get(); slot_drain(crs, S); return ZKG_ERROR; }
+    gC.add(Lt); gC.add(Ht);                                                 // C = H_t + L_t + s A + r B_1 - rs delta
+    lap(S, "G1 side assembled");
+    if (g2_tail.get()) { slot_drain(crs, S); return ZKG_ERROR; }
+    lap(S, "G2 msm finished");
+    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
+    size_t off = 0;
+    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
+    *proof_len = off;
+    lap(S, "assembled+serialised");
+    ZK_HIP(hipStreamSynchronize(s));
+    {
+        float t;
+        auto el = [&](int a, int b) { return hipEventElapsedTime(&t, S.ev[a], S.ev[b]) == hipSuccess ? t : -1.f; };
+        S.stage_ms[0] = el(0, 1); S.stage_ms[1] = el(1, 2); S.stage_ms[2] = el(5, 6); S.stage_ms[3] = el(7, 8); S.stage_ms[4] = el(3, 4);
+        S.stage_ms[5] = el(11, 12); S.stage_ms[6] = el(9, 10);
+        S.stage_ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count();
+        for (int i = 0; i < 8; ++i) crs->stage_ms[i] = S.stage_ms[i];
+    }
     return ZKG_OK;
 }
 
@@ -294,80 +413,9 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !witness)) { set_error("zkg_groth16_prove: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
-    hipStream_t s = crs->stream;
-    const size_t n = crs->n, l = crs->l, m = crs->m;
-    auto t_wall0 = std::chrono::steady_clock::now();
-    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr, serial = getenv("ZKG_SERIAL_MSM") != nullptr;
-    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count()); };
-    uint32_t flag = 0;
-    if (compute_h(crs, witness, check_satisfied != 0, &flag, s)) return ZKG_ERROR;
-    lap("h pipeline enqueued");
-    // ---- multi-exponentiations, concurrently on their own streams.  Scalars are Montgomery Fr on device (converted on the fly).
-    //      A / B_g1 / B_g2 and L only need z (event 0); H needs the NTT pipeline (event 2).
-    const uint32_t *z = crs->z.as<uint32_t>();
-    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
-    struct Launch { MsmJob *job; const G1Affine *g1; const G2Affine *g2; const uint32_t *sc; size_t cnt; int wait_ev, ev0; };
-    const Launch launches[5] = {
-        {crs->job_b2, nullptr, crs->B_g2.as<G2Affine>(), z, n + 1, 0, 3},               // the G2 MSM is the long pole: first
-        {crs->job_a, crs->A_query.as<G1Affine>(), nullptr, z, n + 1, 0, 5},
-        {crs->job_b1, crs->B_g1.as<G1Affine>(), nullptr, z, n + 1, 0, 7},
-        {crs->job_l, crs->L_query.as<G1Affine>(), nullptr, z + 8 * (l + 1), n - l, 0, 9},
-        {crs->job_h, crs->H_query.as<G1Affine>(), nullptr, crs->aABC.as<uint32_t>(), m - 1, 2, 11}};
-    for (const Launch &L : launches) {
-        hipStream_t js = msm_job_stream(L.job);
-        ZK_HIP(hipStreamWaitEvent(js, crs->ev[L.wait_ev], 0));
-        (void)hipEventRecord(crs->ev[L.ev0], js);
-        if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
-        (void)hipEventRecord(crs->ev[L.ev0 + 1], js);
-        if (serial) (void)hipStreamSynchronize(js);                         // profiling aid: one multi-exponentiation at a time
-        lap("  job enqueued");
-    }
-    lap("msm jobs enqueued");
-    // host work that needs only the CRS and (r, s): overlaps the GPU
-    Fr r, sv; memcpy(r.v, r_, 32); memcpy(sv.v, s_, 32);
-    uint32_t rc[8], sc[8], rsc[8];
-    canonical_limbs(r, rc); canonical_limbs(sv, sc); canonical_limbs(r * sv, rsc);
-    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
-    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
-    G1 r_delta1 = delta1.mul(rc, 8), s_delta1 = delta1.mul(sc, 8), rs_delta1 = delta1.mul(rsc, 8);
-    G2 s_delta2 = delta2.mul(sc, 8);
-    lap("crs-only host products");
-    if (check_satisfied) {
-        ZK_HIP(hipStreamSynchronize(s));
-        if (flag) {                                                          // drain the speculative MSMs, then refuse like snark.cpp:121-124
-            for (const Launch &L : launches) (void)hipStreamSynchronize(msm_job_stream(L.job));
-            set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
-        }
-    }
-    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing.
-    //      The three products that involve only the CRS were computed above.  A and B_g1 end early: s*A + r*B_1 - rs*delta (two
-    //      254-bit scalar multiplications, ~0.2 ms) is formed while H is still on the GPU; B_g2's host tail (chunk sums and 255 G2
-    //      doublings, ~0.3 ms) runs on a helper thread.
-    auto g2_tail = std::async(std::launch::async, [&] { return msm_job_finish(crs->job_b2, nullptr, &Bt2); });
-    if (msm_job_finish(crs->job_a, &AB[0], nullptr) || msm_job_finish(crs->job_b1, &AB[1], nullptr)) { (void)g2_tail.get(); return ZKG_ERROR; }
-    G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
-    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
-    G1 gC = gA.mul(sc, 8); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
-    lap("s*A + r*B1 - rs*delta");
-    if (msm_job_finish(crs->job_l, &Lt, nullptr) || msm_job_finish(crs->job_h, &Ht, nullptr)) { (void)g2_tail.get(); return ZKG_ERROR; }
-    gC.add(Lt); gC.add(Ht);                                                 // C = H_t + L_t + s A + r B_1 - rs delta
-    lap("G1 side assembled");
-    if (g2_tail.get()) return ZKG_ERROR;
-    lap("G2 msm finished");
-    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
-    size_t off = 0;
-    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
-    *proof_len = off;
-    lap("assembled+serialised");
-    ZK_HIP(hipStreamSynchronize(s));
-    {
-        float t;
-        auto el = [&](int a, int b) { return hipEventElapsedTime(&t, crs->ev[a], crs->ev[b]) == hipSuccess ? t : -1.f; };
-        crs->stage_ms[0] = el(0, 1); crs->stage_ms[1] = el(1, 2); crs->stage_ms[2] = el(5, 6); crs->stage_ms[3] = el(7, 8); crs->stage_ms[4] = el(3, 4);
-        crs->stage_ms[5] = el(11, 12); crs->stage_ms[6] = el(9, 10);
-        crs->stage_ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count();
-    }
-    return ZKG_OK;
+    ProverSlot &S = crs->slot[0];
+    if (prove_enqueue(crs, S, witness, r_, s_, check_satisfied != 0)) { slot_drain(crs, S); return ZKG_ERROR; }
+    return prove_finish(crs, S, proof_out, proof_len);
 }
 
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
