@@ -50,3 +50,15 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "zkoracle" not in txt and "pyref" not in txt and "oracle/" not in txt, f
+
+
+def test_domain_rule_matches_the_definition_without_a_gpu():
+    """zkg_evaluation_domain_size is pure host code: libfqfft's get_evaluation_domain rule (basic_radix2 / step_radix2) against the
+    table tests/golden/step_domain.json holds (from oracle/pyref.py's restatement of the rule)"""
+    import zklaim_amd as zkg
+    from util import golden
+    for k, kind, m in golden("step_domain.json")["rule"]:
+        assert zkg.evaluation_domain_size(k) == (m, kind == "step"), k
+    for bad in (0, 1, (1 << 28) + 1):
+        with pytest.raises(zkg.ZkgError):
+            zkg.evaluation_domain_size(bad)
