@@ -105,8 +105,8 @@ int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool sc
 // one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0 = 0, uint32_t ws = 1);   // w0, ws: window subset (see MsmGeom)
-int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s);
-int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s);
+int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s, bool scalars_mont = false);
+int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s, bool scalars_mont = false);
 void msm_release_all();
 int msm_configure();
 

@@ -576,35 +576,37 @@ int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mo
 
 // ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, const uint32_t *scalars, size_t n, Affine<F> *out) {
+__global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, const uint32_t *scalars, size_t n, int mont, Affine<F> *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t k[8];
-    for (int j = 0; j < 8; ++j) k[j] = scalars[8 * i + j];
+    Fr f;
+    for (int j = 0; j < 8; ++j) f.v[j] = scalars[8 * i + j];
+    if (mont) f = f.from_mont();                                                // the generator hands over Montgomery Fr; the ABI canonical limbs
+    else f = f.normalized();
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int b = 0; b < 254; ++b)
-        if ((k[b >> 5] >> (b & 31)) & 1u) acc.madd(table[b]);
+        if ((f.v[b >> 5] >> (b & 31)) & 1u) acc.madd(table[b]);
     XYZZ<F> fin = acc;                     // to_affine() is out of line: only this copy has its address taken, the loop's accumulator stays in registers
     out[i] = fin.to_affine().normalized();
 }
 
 template <class F>
-static int fixed_base(const Affine<F> &base, const uint32_t *d_scalars, size_t n, Affine<F> *d_out, hipStream_t s) {
+static int fixed_base(const Affine<F> &base, const uint32_t *d_scalars, size_t n, Affine<F> *d_out, hipStream_t s, bool mont) {
     std::vector<Affine<F>> table(254);
     XYZZ<F> cur = XYZZ<F>::from_affine(base);
     for (int b = 0; b < 254; ++b) { table[b] = cur.to_affine(); cur = cur.dbl(); }
     DevBuf d_table;
     if (d_table.reserve(table.size() * sizeof(Affine<F>))) return ZKG_ERROR;
     ZK_HIP(hipMemcpyAsync(d_table.p, table.data(), table.size() * sizeof(Affine<F>), hipMemcpyHostToDevice, s));
-    if (n) hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_table.as<Affine<F>>(), d_scalars, n, d_out);
+    if (n) hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_table.as<Affine<F>>(), d_scalars, n, (int)mont, d_out);
     hipError_t e = hipGetLastError();
     ZK_HIP(hipStreamSynchronize(s));
     d_table.release();
     if (e != hipSuccess) { set_error("fixed_base launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
-int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s) { return fixed_base<Fq>(base, d_scalars, n, d_out, s); }
-int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s) { return fixed_base<Fq2>(base, d_scalars, n, d_out, s); }
+int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s, bool mont) { return fixed_base<Fq>(base, d_scalars, n, d_out, s, mont); }
+int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s, bool mont) { return fixed_base<Fq2>(base, d_scalars, n, d_out, s, mont); }
 
 int msm_configure() {
     bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;

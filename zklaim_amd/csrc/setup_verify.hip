@@ -62,15 +62,14 @@ void copy_csr(std::vector<uint32_t> &rp, std::vector<uint32_t> &col, std::vector
 template <class A, class FN>
 int batch_points(FN fixed_base_fn, const A &base, const std::vector<Fr> &scalars, std::vector<A> &out) {
     size_t n = scalars.size();
-    out.assign(n, A::inf());
+    out.resize(n);
     if (!n) return ZKG_OK;
-    std::vector<uint32_t> canon(n * 8);
-    for (size_t i = 0; i < n; ++i) { Fr c = scalars[i].from_mont(); memcpy(&canon[8 * i], c.v, 32); }
+    static_assert(sizeof(Fr) == 32, "Fr is the 32-byte Montgomery element the kernel reads");
     DevBuf d_s, d_o;
     if (d_s.reserve(n * 32) || d_o.reserve(n * sizeof(A))) return ZKG_ERROR;
-    int rc = ZKG_ERROR;
-    if (hip_ok(hipMemcpy(d_s.p, canon.data(), n * 32, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
-        fixed_base_fn(base, d_s.as<uint32_t>(), n, d_o.as<A>(), nullptr) == ZKG_OK &&
+    int rc = ZKG_ERROR;                                    // Montgomery scalars go up as they are: the kernel converts (no host pass)
+    if (hip_ok(hipMemcpy(d_s.p, scalars.data(), n * 32, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+        fixed_base_fn(base, d_s.as<uint32_t>(), n, d_o.as<A>(), nullptr, true) == ZKG_OK &&
         hip_ok(hipMemcpy(out.data(), d_o.p, n * sizeof(A), hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) rc = ZKG_OK;
     d_s.release(); d_o.release();
     return rc;
