@@ -122,15 +122,110 @@ def main():
             lines.append(f'    "{i.text}\\n\\t" \\')
         lines.append('    ""')
         lines.append("")
+    for name, (P, INV) in FIELDS.items():
+        for kind, sub in (("ADD", False), ("SUB", True)):
+            lines.append(f"// {name} lazy {kind.lower()}: r = a {'-' if sub else '+'} b kept in [0, 2p), 35 issue slots")
+            lines.append(f"#define ZK_FP_{kind}_ASM_{name} \\")
+            for t in gen_addsub(P, sub):
+                lines.append(f'    "{t}\\n\\t" \\')
+            lines.append('    ""')
+            lines.append("")
+    lines.append("#define ZK_FP_ADDSUB_CLOBBERS " + ", ".join(f'"v{T0 + i}"' for i in range(17)) + ', "vcc"')
     clob = [f'"v{PAIRS[0] + i}"' for i in range(4)] + [f'"v{M0 + i}"' for i in range(8)] + [f'"s{S0 + i}"' for i in range(9)] + ['"vcc"']
     lines.append("#define ZK_MONT_MUL_CLOBBERS " + ", ".join(clob))
     open(dst, "w").write("\n".join(lines) + "\n")
     print("wrote", os.path.normpath(dst))
 
 
-if __name__ == "__main__":
-    main()
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Lazy addition / subtraction on [0, 2p): the compiler's version of these 8-limb carry chains costs ~90 instructions, 32 of them
+# half-rate 64-bit adds (it avoids v_addc chains because gfx950 wants two wait states between a VALU writing a carry and the VALU
+# reading it).  Here two chains are interleaved so that each fills the other's wait states:
+#   add:  t = a + b (carry in an SGPR pair)      s = t - 2p (borrow in vcc, literals)      r = borrow ? t : s
+#   sub:  t = a - b (borrow in an SGPR pair)     s = t + 2p (carry in vcc, literals)       r = borrow ? s : t
+# 35 issue slots, all full rate (the filler slots load the 2p limbs).  Fixed temporaries t = v2..v9, s = v10..v17, v18.  Operands: %0-%7 r, %8 SGPR pair, %9-%16 a, %17-%24 b.
+T0, S0R = 2, 10
+
+
+def gen_addsub(P, sub):
+    two_p = sum(x << (32 * i) for i, x in enumerate(P)) * 2
+    L = [(two_p >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    T = lambda j: f"v{T0 + j}"
+    S = lambda j: f"v{S0R + j}"
+    A = lambda j: f"%{9 + j}"
+    B = lambda j: f"%{17 + j}"
+    K = f"v{S0R + 8}"                               # the 2p limb of the current column (a literal next to a carry-in would be a
+    out = [f"v_mov_b32 {K}, 0x{L[0]:08x}"]         # second constant-bus operand, which VOP2/VOP3 do not allow): loaded in the filler slots
+    for j in range(8):
+        if not sub:
+            out.append(f"v_add_co_u32_e64 {T(j)}, %8, {A(j)}, {B(j)}" if j == 0 else f"v_addc_co_u32_e64 {T(j)}, %8, {A(j)}, {B(j)}, %8")
+            out.append(f"v_subrev_co_u32_e32 {S(j)}, vcc, {K}, {T(j)}" if j == 0 else f"v_subbrev_co_u32_e32 {S(j)}, vcc, {K}, {T(j)}, vcc")
+        else:
+            out.append(f"v_sub_co_u32_e64 {T(j)}, %8, {A(j)}, {B(j)}" if j == 0 else f"v_subb_co_u32_e64 {T(j)}, %8, {A(j)}, {B(j)}, %8")
+            out.append(f"v_add_co_u32_e32 {S(j)}, vcc, {K}, {T(j)}" if j == 0 else f"v_addc_co_u32_e32 {S(j)}, vcc, {K}, {T(j)}, vcc")
+        # third slot of the column: with the other chain's instruction it makes the two wait states a carry needs before it is read again
+        out.append(f"v_mov_b32 {K}, 0x{L[j + 1]:08x}" if j < 7 else "s_nop 0")
+    out.append("s_nop 0")                          # the selects read the last carries: one more slot
+    for j in range(8):
+        # add: borrow (vcc) set  <=>  t < 2p  -> keep t.   v_cndmask_b32_e32 D = vcc ? src1 : src0
+        # sub: borrow (%8) set   <=>  a < b   -> take s.   v_cndmask_b32_e64 D = mask ? src1 : src0
+        out.append(f"v_cndmask_b32_e32 %{j}, {S(j)}, {T(j)}, vcc" if not sub else f"v_cndmask_b32_e64 %{j}, {T(j)}, {S(j)}, %8")
+    return out
+
+
+def simulate_addsub(ins_list, a, b):
+    import re
+    reg = {}
+    M32 = 0xFFFFFFFF
+    for i in range(8):
+        reg[f"%{9 + i}"] = (a >> (32 * i)) & M32
+        reg[f"%{17 + i}"] = (b >> (32 * i)) & M32
+    def val(tok):
+        tok = tok.strip()
+        return int(tok, 16) if tok.startswith("0x") else reg[tok]
+    for text in ins_list:
+        op, _, rest = text.partition(" ")
+        args = [x.strip() for x in rest.split(",")]
+        if op == "s_nop":
+            continue
+        if op == "v_mov_b32":
+            reg[args[0]] = val(args[1]); continue
+        if op in ("v_add_co_u32_e64", "v_add_co_u32_e32"):
+            r = val(args[2]) + val(args[3]); reg[args[0]] = r & M32; reg[args[1]] = r >> 32
+        elif op in ("v_addc_co_u32_e64", "v_addc_co_u32_e32"):
+            r = val(args[2]) + val(args[3]) + reg[args[4]]; reg[args[0]] = r & M32; reg[args[1]] = r >> 32
+        elif op == "v_sub_co_u32_e64":
+            r = val(args[2]) - val(args[3]); reg[args[0]] = r & M32; reg[args[1]] = 1 if r < 0 else 0
+        elif op == "v_subb_co_u32_e64":
+            r = val(args[2]) - val(args[3]) - reg[args[4]]; reg[args[0]] = r & M32; reg[args[1]] = 1 if r < 0 else 0
+        elif op == "v_subrev_co_u32_e32":           # D = src1 - src0
+            r = val(args[3]) - val(args[2]); reg[args[0]] = r & M32; reg[args[1]] = 1 if r < 0 else 0
+        elif op == "v_subbrev_co_u32_e32":
+            r = val(args[3]) - val(args[2]) - reg[args[4]]; reg[args[0]] = r & M32; reg[args[1]] = 1 if r < 0 else 0
+        elif op in ("v_cndmask_b32_e32", "v_cndmask_b32_e64"):
+            reg[args[0]] = val(args[2]) if reg[args[3]] else val(args[1])
+        else:
+            raise ValueError(op)
+    return sum(reg[f"%{j}"] << (32 * j) for j in range(8))
+
+
+def selftest_addsub():
+    import random
+    rnd = random.Random(11)
+    for name, (P, INV) in FIELDS.items():
+        p = sum(x << (32 * i) for i, x in enumerate(P))
+        add, sub = gen_addsub(P, False), gen_addsub(P, True)
+        edge = [0, 1, p - 1, p, p + 1, 2 * p - 1]
+        cases = [(x, y) for x in edge for y in edge] + [(rnd.randrange(2 * p), rnd.randrange(2 * p)) for _ in range(300)]
+        for a, b in cases:
+            r = simulate_addsub(add, a, b)
+            assert r < 2 * p and r % p == (a + b) % p, (name, "add", a, b)
+            r = simulate_addsub(sub, a, b)
+            assert r < 2 * p and r % p == (a - b) % p, (name, "sub", a, b)
+    print("selftest ok: interleaved add / sub streams keep [0, 2p) and agree with (a +- b) mod p for Fq and Fr")
 
 def simulate(ins_list, a, b):
     """Interprets the generated stream on Python ints (one lane).  Returns the 8 result limbs."""
@@ -194,5 +289,7 @@ def selftest():
 
 if __name__ == "__main__":
     import sys
+    main()
     if "--check" in sys.argv:
         selftest()
+        selftest_addsub()

@@ -75,11 +75,30 @@ struct alignas(16) Fp {
         return r;
     }
     friend ZK_HD Fp operator+(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+        // lazy: a, b < 2p, a + b < 4p < 2^256; folded once with 2p.  Two interleaved carry chains (tools/gen_mont_asm.py): 34 full-rate
+        // issue slots against the compiler's ~90 instructions with 32 half-rate 64-bit adds.
+        Fp r; uint64_t c;
+        if constexpr (std::is_same<PR, FqParams>::value) {
+            asm(ZK_FP_ADD_ASM_FQ
+                : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&s"(c)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_FP_ADDSUB_CLOBBERS);
+        } else {
+            asm(ZK_FP_ADD_ASM_FR
+                : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&s"(c)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_FP_ADDSUB_CLOBBERS);
+        }
+        return r;
+#else
         uint32_t t[8]; uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[j] + b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
-        uint32_t s[8]; uint32_t br = 0;                 // lazy: a + b < 4p < 2^256; fold once with 2p
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t s[8]; uint32_t br = 0;                 // lazy (ZK_MONT_CXX build): fold once with 2p
 #pragma unroll
         for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)t[j] - PR::TWO_P[j] - br; s[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
         Fp r;
@@ -89,15 +108,33 @@ struct alignas(16) Fp {
 #else
         return reduce_once(t);               // p < 2^254: a + b < 2^255 never carries out
 #endif
+#endif
     }
     friend ZK_HD Fp operator-(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+        Fp r; uint64_t c;                                // lazy: a - b, plus 2p when it borrowed; same interleaved scheme as operator+
+        if constexpr (std::is_same<PR, FqParams>::value) {
+            asm(ZK_FP_SUB_ASM_FQ
+                : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&s"(c)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_FP_ADDSUB_CLOBBERS);
+        } else {
+            asm(ZK_FP_SUB_ASM_FR
+                : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&s"(c)
+                : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+                  "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+                : ZK_FP_ADDSUB_CLOBBERS);
+        }
+        return r;
+#else
         uint32_t t[8]; uint32_t br = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)a.v[j] - b.v[j] - br; t[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
         uint32_t mask = 0u - br; uint64_t c = 0; Fp r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+#if defined(__HIP_DEVICE_COMPILE__)
             c += (uint64_t)t[j] + (PR::TWO_P[j] & mask);
 #else
             c += (uint64_t)t[j] + (PR::P[j] & mask);
@@ -105,6 +142,7 @@ struct alignas(16) Fp {
             r.v[j] = (uint32_t)c; c >>= 32;
         }
         return r;
+#endif
     }
     ZK_HD Fp neg() const { return zero() - *this; }      // 0 - 0 = 0; otherwise p - a (host) / 2p - a (device, lazy)
     ZK_HD Fp dbl() const { return *this + *this; }
