@@ -242,14 +242,16 @@ def main():
                      "note": "integer-VALU-bound kernel (about 10 Montgomery multiplications per 96 input bytes); see DESIGN.md"},
     }
     if kern_ms > 0:
-        # second, honest roofline for this kernel: vector-ALU issue slots.  One XYZZ mixed addition = ~3900 instructions of which 1280 are
-        # half-rate v_mad_u64_u32 (counted as 2 slots): ~5200 slots; a SIMD retires one full-rate wave-instruction per ~2.6 cycles at the
-        # nominal 2.4 GHz (profiles/r1_microbench_int_issue_rates.txt).  N*W additions per launch, 64 lanes per wave-instruction.
+        # second, honest roofline for this kernel: vector-ALU issue slots.  One XYZZ mixed addition = 10 Montgomery multiplications of 296
+        # instructions (136 of them half-rate v_mad_u64_u32 / v_mul_lo_u32, counted as 2 slots: 432 slots each) + 8 lazy additions /
+        # subtractions of 35 slots + ~130 of loads, sign handling and zero tests: ~4700 slots; a SIMD retires one full-rate
+        # wave-instruction per ~2.6 cycles at the nominal 2.4 GHz (profiles/r1_microbench_int_issue_rates.txt).  N*W additions per launch,
+        # 64 lanes per wave-instruction.
         windows = (255 + 15) // 16 if args.logn >= 20 else None
         if windows:
-            slots = n * windows * 5200.0 / 64.0
+            slots = n * windows * 4700.0 / 64.0
             peak_slots_per_s = cus * 4 * 2.4e9 / 2.6
-            line["valu_roofline"] = {"kernel": "k_bucket_accum<Fq>", "mixed_additions_per_launch": n * windows, "issue_slots_per_addition": 5200,
+            line["valu_roofline"] = {"kernel": "k_bucket_accum<Fq>", "mixed_additions_per_launch": n * windows, "issue_slots_per_addition": 4700,
                                      "achieved_Gadd_per_s": round(n * windows / (kern_ms * 1e-3) / 1e9, 3),
                                      "frac_of_issue_peak": round(slots / (kern_ms * 1e-3) / peak_slots_per_s, 4),
                                      "note": "fraction of the chip's VALU issue capacity at nominal clock; the chip clocks below nominal under this load"}
