@@ -117,9 +117,15 @@ int zkg_ntt_domain_dev(void *d_a, size_t m, int inverse, int coset, void *stream
  *      in [0, r).  out: normalised jac.                                               */
 int zkg_msm_g1(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[12]);
 int zkg_msm_g2(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_jac[24]);
-/* device-resident inputs; scalars_mont != 0 means the scalars are Montgomery Fr (a
- * witness vector) and are converted on the fly.  The result is written to HOST memory
- * (out_jac) after the stream is synchronised.                                         */
+/* device-resident inputs.  scalars_mont is a set of flags:
+ *   ZKG_SCALARS_MONT         the scalars are Montgomery Fr (a witness vector), converted on the fly;
+ *   ZKG_SCALARS_MOSTLY_BITS  the caller knows most scalars are 0 or 1 — libff's
+ *                            multi_exp_with_mixed_addition case (A / B / L queries over a witness), as opposed to plain multi_exp
+ *                            (H query): the digits are then sorted in one pass; the two-pass sort that is faster for uniformly
+ *                            random scalars degrades when half of them share a digit.  The result never depends on the flag.
+ * The result is written to HOST memory (out_jac) after the stream is synchronised.     */
+#define ZKG_SCALARS_MONT 1
+#define ZKG_SCALARS_MOSTLY_BITS 2
 int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
                    uint64_t out_jac[12], void *stream);
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,

@@ -150,3 +150,21 @@ def test_window_sharded_partials_add_up(zkg, oracle, world):
     assert np.array_equal(full, oracle.msm_g1(bases, sc))
     # the default entry point is unaffected by a previous subset call
     assert np.array_equal(zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n), full)
+
+
+def test_mostly_bits_flag_does_not_change_the_result(zkg, oracle):
+    """ZKG_SCALARS_MOSTLY_BITS only selects the one-pass digit sort (libff's multi_exp_with_mixed_addition case); witness-like scalars
+    (bits plus a few full-size values) and uniform ones give the same point either way, equal to the oracle"""
+    import torch
+    n = 70000                                              # c = 16, two-pass sort by default
+    d_b, bases, _ = dev_bases_g1(zkg, n, 91)
+    uni = random_fr_canonical(n, 92)
+    wit = uni.copy()
+    rng = np.random.default_rng(5)
+    bits = rng.random(n) < 0.97
+    wit[bits] = 0; wit[bits, 0] = rng.integers(0, 2, int(bits.sum())).astype(np.uint64)
+    for sc in (uni, wit):
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        a = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n)
+        b = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n, mostly_bits=True)
+        assert np.array_equal(a, b) and np.array_equal(a, oracle.msm_g1(bases, sc, oracle.MIXED))

@@ -146,9 +146,13 @@ def msm_g2(bases, scalars):
     return out
 
 
-def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0):
+SCALARS_MONT, SCALARS_MOSTLY_BITS = 1, 2
+
+
+def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0, mostly_bits=False):
     out = np.zeros(12, np.uint64)
-    _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), int(scalars_mont), _p(out), _vp(stream)), "zkg_msm_g1_dev")
+    flags = (SCALARS_MONT if scalars_mont else 0) | (SCALARS_MOSTLY_BITS if mostly_bits else 0)
+    _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), flags, _p(out), _vp(stream)), "zkg_msm_g1_dev")
     return out
 
 

@@ -243,7 +243,7 @@ int zkg_ntt_domain(uint64_t *a, size_t m, int inverse, int coset) {
 int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
     REQUIRE_INIT();
     G1 r;
-    if (msm_g1((const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    if (msm_g1((const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, (scalars_mont & ZKG_SCALARS_MONT) != 0, &r, (hipStream_t)stream, (scalars_mont & ZKG_SCALARS_MOSTLY_BITS) != 0)) return ZKG_ERROR;
     store_norm(out_jac, r);
     return ZKG_OK;
 }
@@ -252,14 +252,15 @@ int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n,
     REQUIRE_INIT();
     if (!window_stride) { set_error("zkg_msm_g1_windows_dev: window_stride must be positive"); return ZKG_ERROR; }
     G1 r; const G1Affine *b = (const G1Affine *)d_bases;
-    if (msm_shared(&b, 1, nullptr, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, nullptr, (hipStream_t)stream, first_window, window_stride)) return ZKG_ERROR;
+    if (msm_shared(&b, 1, nullptr, (const uint32_t *)d_scalars, n, (scalars_mont & ZKG_SCALARS_MONT) != 0, &r, nullptr, (hipStream_t)stream, first_window, window_stride,
+                   (scalars_mont & ZKG_SCALARS_MOSTLY_BITS) != 0)) return ZKG_ERROR;
     store_norm(out_jac, r);
     return ZKG_OK;
 }
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[24], void *stream) {
     REQUIRE_INIT();
     G2 r;
-    if (msm_g2((const G2Affine *)d_bases, (const uint32_t *)d_scalars, n, scalars_mont != 0, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    if (msm_g2((const G2Affine *)d_bases, (const uint32_t *)d_scalars, n, (scalars_mont & ZKG_SCALARS_MONT) != 0, &r, (hipStream_t)stream, (scalars_mont & ZKG_SCALARS_MOSTLY_BITS) != 0)) return ZKG_ERROR;
     store_norm(out_jac, r);
     return ZKG_OK;
 }

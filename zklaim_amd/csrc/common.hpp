@@ -94,17 +94,19 @@ struct MsmJob;                                             // one MSM in flight:
 MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);
 hipStream_t msm_job_stream(MsmJob *j);
 void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws);   // the job computes sum over windows w0, w0+ws, ... of 2^(cw) V_w only
+void msm_job_set_skewed(MsmJob *j, bool skewed);            // scalars known to be mostly equal (0/1 witness): use the one-pass sort directly
 void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_destroy(MsmJob *j);
 int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);
 // scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  Zero scalars are dropped and ones land in
 // one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
-int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s);
-int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G2 *out, hipStream_t s);
+int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s, bool mostly_bits = false);
+int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G2 *out, hipStream_t s, bool mostly_bits = false);
 // one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0 = 0, uint32_t ws = 1);   // w0, ws: window subset (see MsmGeom)
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0 = 0, uint32_t ws = 1,   // w0, ws: window subset (see MsmGeom)
+               bool mostly_bits = false);                 // the multi_exp_with_mixed_addition case: scalars mostly 0/1 -> one-pass sort
 int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s, bool scalars_mont = false);
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s, bool scalars_mont = false);
 void msm_release_all();

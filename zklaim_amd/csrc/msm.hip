@@ -183,6 +183,182 @@ __global__ __launch_bounds__(SORT_THREADS) void k_place(const uint32_t *digits, 
     }
 }
 
+
+// ---- 4b. two-pass sort (c >= 12, n < 2^22).  k_place's 4-byte stores each leave the L2 as their own 32-byte write (measured: 538 MB of
+//      WRITE_SIZE for a 64 MiB list), so here no pass scatters single words to global memory: pass 1 splits a 16K-point slice into the
+//      64 coarse bins of its window inside LDS and writes each bin's run contiguously; pass 2 takes one (window, coarse bin), sorts its
+//      ~n/64 entries by the remaining bucket bits inside LDS and writes the final list — and the bucket counts and offsets — in order.
+static constexpr uint32_t RX_MAX_CBITS = 10, RX_MAX_CB = 1u << RX_MAX_CBITS, RX_SLICE = 16384, RX_FINE_MAX = 8192, RX_BIN_AVG = 4096;
+// temporary entry between the passes: fine bucket (fbits) in the top bits | point index << 1 | sign below.  cbits: log2 of the coarse bins
+// per window, chosen on the host so that a bin averages <= 4096 entries, half of what the second pass holds in LDS (measured: 1365 ...
+// 8192 all within 2 %).  The top window of a 254-bit scalar populates only 38 % of its buckets, so its bins are 2.65x as full and go to
+// k_rx_fine_big's plain path.
+__global__ __launch_bounds__(1024) void k_rx_count(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, uint32_t *cnt) {
+    __shared__ uint32_t c[RX_MAX_CB];
+    const uint32_t sl = blockIdx.x, w = blockIdx.y, t = threadIdx.x, CB = 1u << cbits;
+    if (t < CB) c[t] = 0;
+    __syncthreads();
+    size_t lo = (size_t)sl * RX_SLICE, hi = lo + RX_SLICE < n ? lo + RX_SLICE : n;
+    const uint32_t *d = digits + (size_t)w * n;
+    for (size_t i = lo + t; i < hi; i += 1024) { uint32_t code = d[i]; if (code) atomicAdd(&c[((code >> 1) - 1) >> fbits], 1u); }
+    __syncthreads();
+    if (t < CB && c[t]) atomicAdd(&cnt[w * CB + t], c[t]);
+}
+// exclusive scan of the W * 2^cbits bin counts (<= 16384 of them, 16 per thread) -> bin start positions; base[nbins] = number of entries
+__global__ __launch_bounds__(1024) void k_rx_scan(const uint32_t *cnt, uint32_t nbins, uint32_t *base, uint32_t *cursor, uint32_t *grand_total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (nbins + 1023) / 1024, lo = t * per, hi = lo + per < nbins ? lo + per : nbins;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += cnt[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { base[i] = run; cursor[i] = 0; run += cnt[i]; }
+    if (t == 1023) { base[nbins] = part[1023]; *grand_total = part[1023]; }
+}
+__global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, const uint32_t *base, uint32_t *cursor,
+                                                      uint32_t *tmp) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t CB = 1u << cbits;
+    uint32_t *stage = lds_u32, *c = lds_u32 + RX_SLICE, *off = c + RX_MAX_CB, *gb = off + RX_MAX_CB + 1, *cur = gb + RX_MAX_CB;
+    const uint32_t sl = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    if (t < CB) c[t] = 0;
+    __syncthreads();
+    size_t lo = (size_t)sl * RX_SLICE, hi = lo + RX_SLICE < n ? lo + RX_SLICE : n;
+    const uint32_t *d = digits + (size_t)w * n;
+    uint32_t code[RX_SLICE / 1024];                                  // this thread's 16 digits stay in registers between the two passes
+#pragma unroll
+    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) {
+        size_t i = lo + t + (size_t)j * 1024;
+        code[j] = i < hi ? d[i] : 0;
+        if (code[j]) atomicAdd(&c[((code[j] >> 1) - 1) >> fbits], 1u);
+    }
+    __syncthreads();
+    if (t < CB) off[t] = c[t];                                       // exclusive scan of the bin counts (Hillis-Steele), off[CB] = entries of the slice
+    __syncthreads();
+    for (uint32_t dd = 1; dd < CB; dd <<= 1) {
+        uint32_t x = (t < CB && t >= dd) ? off[t - dd] : 0;
+        __syncthreads();
+        if (t < CB) off[t] += x;
+        __syncthreads();
+    }
+    if (t == CB - 1) off[CB] = off[t];
+    __syncthreads();
+    if (t < CB) off[t] -= c[t];
+    if (t < CB) { gb[t] = c[t] ? base[w * CB + t] + atomicAdd(&cursor[w * CB + t], c[t]) : 0; cur[t] = 0; }
+    __syncthreads();
+    const uint32_t fmask = (1u << fbits) - 1;
+#pragma unroll
+    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) {
+        if (!code[j]) continue;
+        uint32_t i = (uint32_t)(lo + t + (size_t)j * 1024), b = (code[j] >> 1) - 1, k = b >> fbits;
+        uint32_t pos = off[k] + atomicAdd(&cur[k], 1u);
+        stage[pos] = ((b & fmask) << (32 - fbits)) | (i << 1) | (code[j] & 1u);
+    }
+    __syncthreads();
+    const uint32_t total = off[CB];
+    for (uint32_t p = t; p < total; p += 1024) {                      // runs go out contiguously: consecutive p of one bin are consecutive addresses
+        uint32_t k = 0;
+        for (uint32_t step = CB / 2; step; step >>= 1) if (off[k + step] <= p) k += step;         // the largest k with off[k] <= p: the bin p falls in
+        tmp[gb[k] + (p - off[k])] = stage[p];
+    }
+}
+// shared by the two second-pass kernels: exclusive scan of the FB <= 512 counters (Hillis-Steele in LDS), counts / offsets to global
+ZK_D void rx_fine_offsets(uint32_t *cf, uint32_t *of, uint32_t FB, uint32_t t, uint32_t start, size_t gb0, uint32_t *counts, uint32_t *offsets) {
+    if (t < FB) of[t] = cf[t];
+    __syncthreads();
+    for (uint32_t d = 1; d < FB; d <<= 1) {
+        uint32_t x = (t < FB && t >= d) ? of[t - d] : 0;
+        __syncthreads();
+        if (t < FB) of[t] += x;
+        __syncthreads();
+    }
+    if (t < FB) of[t] -= cf[t];
+    __syncthreads();
+    for (uint32_t f = t; f < FB; f += 1024) { counts[gb0 + f] = cf[f]; offsets[gb0 + f] = start + of[f]; }
+}
+// second pass, one workgroup per (window, coarse bin) whose entries fit LDS (every bin of uniformly random scalars): entries stay in
+// registers between the count and the placement, the sorted bin is assembled in LDS and written out in order
+__global__ __launch_bounds__(1024) void k_rx_fine(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts, uint32_t *offsets,
+                                                   uint32_t *sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
+    uint32_t *bufB = lds_u32, *cf = bufB + RX_FINE_MAX, *of = cf + FB, *cur = of + FB;       // 64 KiB + counters: two workgroups per CU
+    const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
+    const uint32_t start = base[bin], cnt = base[bin + 1] - start;
+    if (cnt > RX_FINE_MAX) return;                                    // k_rx_fine_big's
+    const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
+    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
+    __syncthreads();
+    uint32_t ent[RX_FINE_MAX / 1024];
+#pragma unroll
+    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
+        uint32_t p = t + j * 1024;
+        ent[j] = p < cnt ? tmp[start + p] : 0xffffffffu;
+        if (p < cnt) atomicAdd(&cf[ent[j] >> sh], 1u);
+    }
+    __syncthreads();
+    rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
+#pragma unroll
+    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
+        if (t + j * 1024 >= cnt) continue;
+        uint32_t e = ent[j], f = e >> sh;
+        bufB[of[f] + atomicAdd(&cur[f], 1u)] = e & low;
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < cnt; p += 1024) sorted[start + p] = bufB[p];
+}
+// the bins k_rx_fine left: more entries than LDS holds, i.e. many equal digits (a 0/1 witness without ZKG_SCALARS_MOSTLY_BITS, adversarial
+// input).  One workgroup streams the bin twice; lanes of a wavefront that hold the same fine bucket share one LDS atomic and get
+// consecutive positions, so the stores of the dominant bucket are coalesced.
+__global__ __launch_bounds__(1024) void k_rx_fine_big(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts,
+                                                       uint32_t *offsets, uint32_t *sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
+    uint32_t *cf = lds_u32, *of = cf + FB, *cur = of + FB;
+    const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
+    const uint32_t start = base[bin], cnt = base[bin + 1] - start;
+    if (cnt <= RX_FINE_MAX) return;
+    const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
+    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
+    __syncthreads();
+    const bool giant = cnt > 8 * RX_FINE_MAX;                         // many equal digits; below that (a dense top window) plain atomics are faster
+    if (!giant) {
+        for (uint32_t p = t; p < cnt; p += 1024) atomicAdd(&cf[tmp[start + p] >> sh], 1u);
+    } else
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 1024) {
+        uint32_t p = p0 + t; bool live = p < cnt; uint32_t f = live ? tmp[start + p] >> sh : 0;
+        while (__any(live)) {
+            uint32_t lf = __shfl(f, __ffsll((long long)__ballot(live)) - 1, 64);
+            unsigned long long same = __ballot(live && f == lf);
+            if (live && f == lf) { if ((same & ((1ull << (threadIdx.x & 63)) - 1)) == 0) atomicAdd(&cf[lf], (uint32_t)__popcll(same)); live = false; }
+        }
+    }
+    __syncthreads();
+    rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
+    if (!giant) {
+        for (uint32_t p = t; p < cnt; p += 1024) { uint32_t e = tmp[start + p], f = e >> sh; sorted[start + of[f] + atomicAdd(&cur[f], 1u)] = e & low; }
+        return;
+    }
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 1024) {
+        uint32_t p = p0 + t; bool live = p < cnt; uint32_t e = live ? tmp[start + p] : 0, f = e >> sh;
+        while (__any(live)) {
+            uint32_t lf = __shfl(f, __ffsll((long long)__ballot(live)) - 1, 64);
+            unsigned long long same = __ballot(live && f == lf), below = same & ((1ull << (threadIdx.x & 63)) - 1);
+            uint32_t basepos = 0;
+            if (live && f == lf && below == 0) basepos = atomicAdd(&cur[lf], (uint32_t)__popcll(same));
+            basepos = __shfl(basepos, __ffsll((long long)same) - 1, 64);
+            if (live && f == lf) { sorted[start + of[lf] + basepos + (uint32_t)__popcll(below)] = e & low; live = false; }
+        }
+    }
+}
+
 // Heavy threshold, computed on the device from the real list lengths: a lane walks its bucket's list alone (~7 us per G1
 // addition at low occupancy), so the longest non-heavy list bounds the kernel's latency however little total work there is.
 // Lists are cut at 4x the true average length + 32 (the partly filled top window of uniform scalars averages ~2.7x the other
@@ -392,10 +568,11 @@ struct MsmSlot {                    // per base set: accumulators and the host l
 };
 struct MsmJob {
     hipStream_t stream = nullptr; bool own_stream = false;
-    DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted;
+    DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted, rx_tmp, rx_meta;
     MsmSlot slot[3]; int nslots = 0;
     MsmGeom g{}; size_t n = 0; int red_l_log = RED_L_LOG_SMALL;
     int window_hint = 0;               // 0: pick_geom's rule
+    bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     int empty_g1 = 0; bool empty_g2 = false;
     std::mutex mu;
@@ -479,12 +656,32 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
     uint32_t *digits = job->digits.as<uint32_t>(), *hist = job->hist.as<uint32_t>(), *counts = job->counts.as<uint32_t>(),
              *offsets = job->offsets.as<uint32_t>(), *sums = job->scan_sums.as<uint32_t>(), *chist = job->class_hist.as<uint32_t>();
     if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, g, digits);
+    static const bool radix_off = getenv("ZKG_SORT_ONE_PASS") != nullptr;                       // A/B switch
+    uint32_t cbits = 6;
+    static const uint32_t bin_avg = getenv("ZKG_RX_AVG") ? (uint32_t)atoi(getenv("ZKG_RX_AVG")) : RX_BIN_AVG;     // tuning aid
+    while (cbits < RX_MAX_CBITS && cbits + 1 < g.c - 1 && (n >> cbits) > bin_avg) ++cbits;  // bins average <= RX_BIN_AVG entries where possible, fbits >= 2
+    const bool two_pass = !radix_off && !job->one_pass_sort && g.c >= 12 && n >= 4096 && (n >> cbits) <= RX_FINE_MAX && n <= ((size_t)1 << (31 - (g.c - 1 - cbits)));
+    if (two_pass) {
+        // two-pass sort: 2^cbits coarse bins per window, then the remaining fbits inside LDS
+        const uint32_t fbits = g.c - 1 - cbits, CB = 1u << cbits, nbins = g.W * CB, S1 = (uint32_t)((n + RX_SLICE - 1) / RX_SLICE);
+        if (job->rx_tmp.reserve(n * g.W * 4) || job->rx_meta.reserve((3 * (size_t)nbins + 8) * 4)) return ZKG_ERROR;
+        uint32_t *cnt = job->rx_meta.as<uint32_t>(), *base = cnt + nbins, *cursor = base + nbins + 1, *tmp = job->rx_tmp.as<uint32_t>();
+        ZK_HIP(hipMemsetAsync(cnt, 0, (3 * (size_t)nbins + 8) * 4, s));
+        hipLaunchKernelGGL(k_rx_count, dim3(S1, g.W), dim3(1024), 0, s, digits, n, fbits, cbits, cnt);
+        hipLaunchKernelGGL(k_rx_scan, dim3(1), dim3(1024), 0, s, cnt, nbins, base, cursor, offsets + total);
+        hipLaunchKernelGGL(k_rx_scatter, dim3(S1, g.W), dim3(1024), (RX_SLICE + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
+        hipLaunchKernelGGL(k_rx_fine, dim3(CB, g.W), dim3(1024), (RX_FINE_MAX + 3 * (1u << fbits)) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
+                           job->sorted.as<uint32_t>());
+        hipLaunchKernelGGL(k_rx_fine_big, dim3(CB, g.W), dim3(1024), 3 * (1u << fbits) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
+                           job->sorted.as<uint32_t>());
+    } else {                                                                                    // one pass: histogram, scans, k_place
     hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist);
     hipLaunchKernelGGL(k_colscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hist, g.B, S, total, counts);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblk), dim3(1024), 0, s, counts, offsets, sums, total);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, (uint32_t)nblk, offsets + total);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, offsets, sums, total);
     hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist, offsets, job->sorted.as<uint32_t>());
+    }
     ZK_HIP(hipMemsetAsync(chist, 0, (HEAVY_T_MAX + 2) * 4, s));
     hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, chist, offsets, total);
@@ -505,11 +702,12 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     return j;
 }
 void msm_job_set_window(MsmJob *j, int c) { if (j) j->window_hint = c; }
+void msm_job_set_skewed(MsmJob *j, bool skewed) { if (j) j->one_pass_sort = skewed; }
 void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws) { if (j) { j->w0 = w0; j->ws = ws ? ws : 1; } }
 hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
 void msm_job_destroy(MsmJob *j) {
     if (!j) return;
-    for (DevBuf *b : {&j->digits, &j->hist, &j->counts, &j->offsets, &j->scan_sums, &j->class_hist, &j->order, &j->sorted}) b->release();
+    for (DevBuf *b : {&j->digits, &j->hist, &j->counts, &j->offsets, &j->scan_sums, &j->class_hist, &j->order, &j->sorted, &j->rx_tmp, &j->rx_meta}) b->release();
     for (auto &sl : j->slot) sl.release();
     if (j->own_stream) (void)hipStreamDestroy(j->stream);
     delete j;
@@ -560,18 +758,18 @@ int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
 
 
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
-               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0, uint32_t ws) {
+               bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0, uint32_t ws, bool mostly_bits) {
     std::lock_guard<std::mutex> lk(g_default_job.mu);
-    g_default_job.stream = s; g_default_job.w0 = w0; g_default_job.ws = ws ? ws : 1;
+    g_default_job.stream = s; g_default_job.w0 = w0; g_default_job.ws = ws ? ws : 1; g_default_job.one_pass_sort = mostly_bits;
     if (msm_job_launch(&g_default_job, d_g1_bases, n_g1, d_g2_bases, d_scalars, n, scalars_mont)) return ZKG_ERROR;
     return msm_job_finish(&g_default_job, out_g1, out_g2);
 }
 
-int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
-    return msm_shared(&d_bases, 1, nullptr, d_scalars, n, mont, out, nullptr, s);
+int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G1 *out, hipStream_t s, bool mostly_bits) {
+    return msm_shared(&d_bases, 1, nullptr, d_scalars, n, mont, out, nullptr, s, 0, 1, mostly_bits);
 }
-int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G2 *out, hipStream_t s) {
-    return msm_shared(nullptr, 0, d_bases, d_scalars, n, mont, nullptr, out, s);
+int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G2 *out, hipStream_t s, bool mostly_bits) {
+    return msm_shared(nullptr, 0, d_bases, d_scalars, n, mont, nullptr, out, s, 0, 1, mostly_bits);
 }
 
 // ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
@@ -615,12 +813,14 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_FINE_MAX + 3 * 1024) * 4) == hipSuccess;
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 void msm_release_all() {
     MsmJob &j = g_default_job;
     std::lock_guard<std::mutex> lk(j.mu);
-    for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted}) b->release();
+    for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted, &j.rx_tmp, &j.rx_meta}) b->release();
     for (auto &sl : j.slot) sl.release();
 }
 

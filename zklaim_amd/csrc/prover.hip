@@ -227,6 +227,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
             int w1 = cw ? atoi(cw) : 12, w2 = c2 ? atoi(c2) : w1;
             for (MsmJob *j : {S.job_a, S.job_b1, S.job_l}) msm_job_set_window(j, w1);
             msm_job_set_window(S.job_b2, w2);
+            for (MsmJob *j : {S.job_a, S.job_b1, S.job_b2, S.job_l}) msm_job_set_skewed(j, true);      // 0/1 witness: one heavy bucket per job
         }
     }
     if (ok) {
