@@ -8,12 +8,15 @@
 // not atomic, so on the GPU the scatter is removed structurally — a counting sort by (window, bucket)
 // followed by conflict-free accumulation:
 //   1. k_digits        signed c-bit digits of every scalar, written window-major (4 B per digit)
-//   2. k_hist          one workgroup per (window, 64K-point slice): histogram of its digits in LDS
-//                      (2^(c-1) counters, up to 128 KiB of the CU's 160 KiB) -> hist[w][slice][bucket]
-//   3. k_colscan+scan  per-bucket totals and slice-relative offsets; exclusive scan -> bucket offsets
-//   4. k_place         same workgroup shape as 2: bucket cursors staged in LDS, point indices (sign in
-//                      bit 0) written to their final position.  No global atomics anywhere in the sort,
-//                      so skewed digits (bit witnesses, the short top window) cost nothing extra.
+//   2-4. the sort, in one of two forms (sort_digits picks):
+//        two-pass (uniform scalars, 4096 <= n < 2^23, c >= 12): k_rx_count / k_rx_scan count and lay out coarse bins of buckets per
+//                      window; k_rx_scatter splits each 16K-point slice into those bins inside LDS and writes every bin's run
+//                      contiguously; k_rx_fine sorts one bin by the remaining bucket bits inside LDS and writes the final list and
+//                      the bucket counts / offsets in order.  No single-word scatter to global memory anywhere.
+//        one-pass (small or huge n, small c, ZKG_SCALARS_MOSTLY_BITS): k_hist — one workgroup per (window, 64K-point slice),
+//                      histogram in LDS (2^(c-1) counters, up to 128 KiB of the CU's 160 KiB); k_colscan + block scan -> bucket
+//                      offsets; k_place — bucket cursors staged in LDS, point indices (sign in bit 0) stored at their final
+//                      position.  No global atomics, so skewed digits (bit witnesses) cost nothing extra.
 //   5. k_order         bucket ids ordered by descending length, so the 64 lanes of a wavefront walk
 //                      lists of (nearly) equal length
 //   6. k_bucket_accum  one lane per bucket: sequential XYZZ mixed adds over its index list, next base
