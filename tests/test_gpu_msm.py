@@ -157,6 +157,25 @@ def test_mostly_bits_flag_does_not_change_the_result(zkg, oracle):
     (bits plus a few full-size values) and uniform ones give the same point either way, equal to the oracle"""
     import torch
     n = 70000                                              # c = 16, two-pass sort by default
+    _mostly_bits_case(zkg, oracle, n)
+
+
+def test_two_pass_sort_giant_bin(zkg, oracle):
+    """200 000 witness-like scalars without the hint: ~97 000 ones share one bucket, so one coarse bin holds > 8 x 8192 entries and
+    goes through k_rx_fine_big's wavefront-aggregated path; all-equal scalars put EVERY entry of a window in one bucket"""
+    import torch
+    _mostly_bits_case(zkg, oracle, 200000)
+    n = 150000
+    d_b, bases, _ = dev_bases_g1(zkg, n, 93)
+    same = np.tile(random_fr_canonical(1, 94), (n, 1))
+    d_sc = torch.from_numpy(same.view(np.int64)).cuda()
+    got = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n)
+    assert np.array_equal(got, zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n, mostly_bits=True))
+    assert np.array_equal(got, oracle.msm_g1(bases, same, oracle.BDLO12, oracle.num_threads()))
+
+
+def _mostly_bits_case(zkg, oracle, n):
+    import torch
     d_b, bases, _ = dev_bases_g1(zkg, n, 91)
     uni = random_fr_canonical(n, 92)
     wit = uni.copy()
