@@ -34,7 +34,7 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 struct ProverSlot {
     zk::DevBuf z, aABC, flag;                   // [1 | w] and aA | aB | aC back to back (batched NTTs)
     zk::DevBuf ntt_scratch;                     // inter-pass scratch, 3 m elements
-    hipStream_t stream = nullptr;               // mat-vec + NTT stream (highest priority: the H multi-exponentiation waits on it)
+    hipStream_t stream = nullptr;               // mat-vec + NTT stream
     zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;
     hipEvent_t ev[20]; bool ev_ok = false, ready = false;
     float stage_ms[8] = {0};
@@ -216,9 +216,12 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
-        ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate", __FILE__, __LINE__);
-        S.job_a = msm_job_create(nullptr, true); S.job_b1 = msm_job_create(nullptr, true); S.job_b2 = msm_job_create(nullptr, true);
-        S.job_h = msm_job_create(nullptr, true, true); S.job_l = msm_job_create(nullptr, true);
+        // Stream priorities, measured over eight assignments (8 and 38 payloads): the witness multi-exponentiations high, the mat-vec /
+        // NTT stream and H low is the best one (2.41-2.48 ms against 2.49-2.60 with the H path high, 2.8+ with everything equal):
+        // the latency-bound witness kernels get their few wavefronts placed at once, and the wide NTT / H kernels fill what is left.
+        ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_lo), "hipStreamCreate", __FILE__, __LINE__);
+        S.job_a = msm_job_create(nullptr, true, true); S.job_b1 = msm_job_create(nullptr, true, true); S.job_b2 = msm_job_create(nullptr, true, true);
+        S.job_h = msm_job_create(nullptr, true, false); S.job_l = msm_job_create(nullptr, true, true);
         ok = ok && S.job_a && S.job_b1 && S.job_b2 && S.job_h && S.job_l;
         if (ok) {
             // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
