@@ -227,7 +227,8 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
             // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
             // mostly 0/1 scalars (one heavy bucket) and few full-size ones, so their time is the bucket reduction's: small windows.
             const char *cw = getenv("ZKG_MSM_C_W"), *c2 = getenv("ZKG_MSM_C_G2");           // tuning aids
-            int w1 = cw ? atoi(cw) : 12, w2 = c2 ? atoi(c2) : w1;
+            int lg = 0; while (((size_t)1 << (lg + 1)) <= n + 1) ++lg;
+            int w1 = cw ? atoi(cw) : (lg <= 15 ? 10 : lg <= 18 ? 11 : 12), w2 = c2 ? atoi(c2) : w1;      // measured at 1 / 8 / 38 payloads
             for (MsmJob *j : {S.job_a, S.job_b1, S.job_l}) msm_job_set_window(j, w1);
             msm_job_set_window(S.job_b2, w2);
             for (MsmJob *j : {S.job_a, S.job_b1, S.job_b2, S.job_l}) msm_job_set_skewed(j, true);      // 0/1 witness: one heavy bucket per job
