@@ -265,11 +265,11 @@ __global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, siz
         stage[pos] = ((b & fmask) << (32 - fbits)) | (i << 1) | (code[j] & 1u);
     }
     __syncthreads();
-    const uint32_t total = off[CB];
-    for (uint32_t p = t; p < total; p += 1024) {                      // runs go out contiguously: consecutive p of one bin are consecutive addresses
-        uint32_t k = 0;
-        for (uint32_t step = CB / 2; step; step >>= 1) if (off[k + step] <= p) k += step;         // the largest k with off[k] <= p: the bin p falls in
-        tmp[gb[k] + (p - off[k])] = stage[p];
+    // runs go out contiguously, one wavefront per bin at a time (consecutive lanes -> consecutive addresses)
+    const uint32_t wave = t >> 6, lane = t & 63;
+    for (uint32_t k = wave; k < CB; k += 16) {
+        const uint32_t a = off[k], b = off[k + 1], g = gb[k];
+        for (uint32_t p = a + lane; p < b; p += 64) tmp[g + (p - a)] = stage[p];
     }
 }
 // shared by the two second-pass kernels: exclusive scan of the FB <= 512 counters (Hillis-Steele in LDS), counts / offsets to global
