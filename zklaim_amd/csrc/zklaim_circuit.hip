@@ -12,6 +12,7 @@
 #include "../../include/zkg.h"
 #include "../../include/zklaim_abi.h"
 #include "host/gadgets.hpp"
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -177,27 +178,38 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         sha256_compress_from_iv(pb, block, h_bits[i]);
     };
     if (k > 1 && !getenv("ZKG_SERIAL_CIRCUIT")) {                                  // (the env switch keeps the serial pass available to the tests)
-        // The k sub-circuits allocate the same number of variables each and touch disjoint ranges, so payload 0 runs here (and measures
-        // that number) and payloads 1..k-1 run on the host thread pool through views of the pre-sized storage; constraints recorded by
-        // the views are appended in payload order, which makes the system identical to the one a serial pass records.
-        const uint32_t before = pb.num_variables();
-        const size_t cons_before = pb.cons.size(), terms_before = pb.arena.size();
-        payload_gadgets(pb, 0);
-        const uint32_t per = pb.num_variables() - before;
-        const size_t cons_per = pb.cons.size() - cons_before, terms_per = pb.arena.size() - terms_before;
-        if (pb.recording) { pb.cons.reserve(pb.cons.size() + cons_per * (k - 1)); pb.arena.reserve(pb.arena.size() + terms_per * (k - 1)); }
-        const uint32_t first = pb.extend((size_t)per * (k - 1));
-        std::vector<char> bad(k, 0);
-        std::vector<Builder> views(k - 1);
-        host_parallel_for((int)k - 1, [&](int t) {
+        // The k sub-circuits allocate the same number of variables each and touch disjoint ranges: they run on the host thread pool
+        // through views of the pre-sized storage; constraints recorded by the views are appended in payload order, which makes the
+        // system identical to the one a serial pass records.  The per-payload sizes are a property of the circuit, measured once per
+        // process (payload 0 on this thread, the rest in parallel) and remembered, so that later passes start all k at once.
+        static std::atomic<uint32_t> known_vars{0}, known_cons{0}, known_terms{0};
+        uint32_t per = known_vars.load();
+        size_t cons_per = known_cons.load(), terms_per = known_terms.load();
+        size_t first_parallel = 0;
+        if (!per || (pb.recording && !cons_per)) {                                  // sizes not measured yet (for this kind of pass)
+            const uint32_t before = pb.num_variables();
+            const size_t cons_before = pb.cons.size(), terms_before = pb.arena.size();
+            payload_gadgets(pb, 0);
+            per = pb.num_variables() - before;
+            if (pb.recording) { cons_per = pb.cons.size() - cons_before; terms_per = pb.arena.size() - terms_before; }
+            first_parallel = 1;
+        }
+        const size_t np = k - first_parallel;                                       // payloads first_parallel .. k-1 go to the pool
+        if (pb.recording) { pb.cons.reserve(pb.cons.size() + cons_per * np); pb.arena.reserve(pb.arena.size() + terms_per * np); }
+        const uint32_t first = pb.extend((size_t)per * np);
+        std::vector<char> bad(np, 0);
+        std::vector<Builder> views(np);
+        host_parallel_for((int)np, [&](int t) {
             Builder &v = views[t];
             v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
             if (v.recording) { v.cons.reserve(cons_per); v.arena.reserve(terms_per); }
-            payload_gadgets(v, (size_t)t + 1);
-            bad[t + 1] = v.cursor != v.cursor_end;
+            payload_gadgets(v, (size_t)t + first_parallel);
+            bad[t] = v.cursor != v.cursor_end;
         });
-        for (char b : bad) if (b) { delete ck; set_error("zklaim circuit: payload sub-circuits differ in size"); return nullptr; }
+        for (char b : bad) if (b) { known_vars = 0; delete ck; set_error("zklaim circuit: payload sub-circuits differ in size"); return nullptr; }
         if (pb.recording) for (const Builder &v : views) pb.absorb(v);
+        known_vars = per;
+        if (pb.recording && cons_per) { known_cons = (uint32_t)cons_per; known_terms = (uint32_t)terms_per; }
     } else {
         for (size_t i = 0; i < k; ++i) payload_gadgets(pb, i);
     }
