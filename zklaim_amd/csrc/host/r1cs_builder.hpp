@@ -60,7 +60,13 @@ struct Builder {
     void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = !x.is_zero(); }
     void set_bit(Var v, bool b) { Builder &r = root ? *root : *this; r.val[v] = b ? Fr::one() : Fr::zero(); r.nz[v] = b; }
     bool is_nonzero(Var v) const { return (root ? root : this)->nz[v] != 0; }
-    std::vector<Var> alloc_n(size_t n) { std::vector<Var> v(n); for (auto &x : v) x = alloc(); return v; }
+    std::vector<Var> alloc_n(size_t n) {
+        std::vector<Var> v(n);
+        if (root) { for (auto &x : v) x = alloc(); return v; }
+        const Var first = (Var)extend(n);                                 // one resize instead of n push_backs
+        for (size_t i = 0; i < n; ++i) v[i] = first + (Var)i;
+        return v;
+    }
     void set_input_sizes(uint32_t n) { num_inputs = n; }
     uint32_t num_variables() const { return (uint32_t)val.size() - 1; }
     Span put(const LC &l) { Span sp{(uint32_t)arena.size(), (uint32_t)l.t.size()}; arena.insert(arena.end(), l.t.begin(), l.t.end()); return sp; }
