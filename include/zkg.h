@@ -166,6 +166,11 @@ void     zkg_crs_free(zkg_crs *crs);
  *      ZKG_UNSATISFIED without proving.                                                */
 int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_t r[4],
                       const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
+/* The same proof from a sparse description of the witness: tags[n] (0 = zero, 1 = one, 2 = listed) and `count` listed variables
+ * as (index in 0..n-1, value as 4 Montgomery limbs).  For witness generators that know their bits (zkg_circuit_sparse_witness): the
+ * host-to-device upload shrinks ~30x.  Proof bytes are identical to zkg_groth16_prove on the expanded vector. */
+int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
+                             const uint64_t r[4], const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */
 int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_out);
 /* per-stage device milliseconds of the last zkg_groth16_prove on this crs (the five MSMs run
@@ -185,6 +190,7 @@ uint32_t zkg_circuit_num_variables(const zkg_circuit *c);
 void zkg_circuit_free(zkg_circuit *c);
 int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out);        /* pointers stay valid until zkg_circuit_free            */
 const uint64_t *zkg_circuit_witness(const zkg_circuit *c);        /* num_variables x 4 limbs (NULL without witness)        */
+int zkg_circuit_sparse_witness(const zkg_circuit *c, const uint8_t **tags, const uint32_t **full_index, const uint64_t **full_values, size_t *count);
 int zkg_circuit_is_satisfied(const zkg_circuit *c);               /* pb.is_satisfied() (snark.cpp:121)                     */
 long zkg_circuit_first_unsatisfied(const zkg_circuit *c);         /* index of the first violated constraint, -1 if none    */
 size_t zkg_zklaim_input_map(const struct zklaim_ctx *ctx, uint64_t *out, size_t cap_elems);   /* returns the element count */

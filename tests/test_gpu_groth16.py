@@ -123,3 +123,29 @@ def test_prove_real_zklaim_circuit(zkg, oracle):
     assert rc == 1
     crs.free()
 
+
+def test_prove_sparse_witness_matches_dense(zkg):
+    """zkg_groth16_prove_sparse (tags + listed values, what the seam uploads) gives the same proof bytes as the dense witness; a
+    tampered tag is an unsatisfied system (rc 1); tags agree with the dense vector"""
+    keep = []
+    pls = [dict(attrs=[1994 + i, 7, 42, 0, 5], refs=[2100, 7, 41, 0, 0], ops=["less", "eq", "greater", "noop", "noop"], salt=0xABC + i) for i in range(2)]
+    ck = zkg.ZklaimCircuit(zkg.make_ctx(pls, keep))
+    assert ck.is_satisfied()
+    w = ck.witness()
+    tags, idx, vals = ck.sparse_witness()
+    one = arr([1], R)[0]
+    assert np.array_equal(tags == 0, ~w.any(axis=1)) and np.array_equal(tags == 1, (w == one).all(axis=1))
+    assert np.array_equal(w[idx], vals) and int((tags == 2).sum()) == idx.size and 0 < idx.size < 0.1 * tags.size
+    kp = zkg.Keypair(ck.r1cs, random_fr_canonical(5, 0x5BA))
+    crs = zkg.Crs(kp.pk)
+    rs = random_fr_canonical(2, 0x5BB)
+    rc, dense = crs.prove(w, rs[0], rs[1])
+    rc2, sparse = crs.prove_sparse(tags, idx, vals, rs[0], rs[1])
+    assert rc == 0 and rc2 == 0 and dense == sparse
+    assert zkg.groth16_verify(kp.vk_blob(), w[:ck.r1cs.num_inputs], sparse) == 0
+    bad = tags.copy(); k = int(np.flatnonzero(tags == 1)[-1]); bad[k] = 0
+    rc3, _ = crs.prove_sparse(bad, idx, vals, rs[0], rs[1])
+    assert rc3 == 1
+    rc4, again = crs.prove(w, rs[0], rs[1])
+    assert rc4 == 0 and again == dense
+    crs.free(); kp.free()

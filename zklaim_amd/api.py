@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "libzkg.so")
 DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_evaluation_domain_size", "zkg_ntt_domain", "zkg_ntt_domain_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_msm_g1_windows_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
-    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
+    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_groth16_prove_sparse", "zkg_circuit_sparse_witness", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
@@ -246,6 +246,16 @@ class Crs:
             _check(rc, "zkg_groth16_prove")
         return rc, bytes(out[:ln.value])
 
+    def prove_sparse(self, tags, full_index, full_values, r, s, check_satisfied=True):
+        """zkg_groth16_prove_sparse: tags uint8[n] (0 zero, 1 one, 2 listed), listed variables as (index, 4 Montgomery limbs)"""
+        tags = np.ascontiguousarray(tags, np.uint8); full_index = np.ascontiguousarray(full_index, np.uint32); full_values = _u64(full_values)
+        out = np.zeros(256, np.uint8); ln = C.c_size_t(0)
+        rc = lib().zkg_groth16_prove_sparse(C.c_void_p(self._h), _p(tags), _p(full_index), _p(full_values), C.c_size_t(full_index.size), _p(_u64(r)), _p(_u64(s)),
+                                            int(check_satisfied), _p(out), C.byref(ln))
+        if rc not in (0, 1):
+            _check(rc, "zkg_groth16_prove_sparse")
+        return rc, bytes(out[:ln.value])
+
     def qap_witness_h(self, witness):
         out = np.zeros((self.m + 1, 4), np.uint64)
         _check(lib().zkg_qap_witness_h(C.c_void_p(self._h), _p(_u64(witness)), _p(out)), "zkg_qap_witness_h")
@@ -350,6 +360,16 @@ class ZklaimCircuit:
             return None
         n = self.r1cs.num_variables
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4)).copy()
+
+    def sparse_witness(self):
+        """-> (tags uint8[n], full_index uint32[count], full_values uint64[count,4]): the witness as zkg_groth16_prove_sparse takes it"""
+        tags = C.POINTER(C.c_uint8)(); idx = C.POINTER(C.c_uint32)(); vals = C.POINTER(C.c_uint64)(); cnt = C.c_size_t(0)
+        _check(lib().zkg_circuit_sparse_witness(C.c_void_p(self._h), C.byref(tags), C.byref(idx), C.byref(vals), C.byref(cnt)), "zkg_circuit_sparse_witness")
+        n, c = self.r1cs.num_variables, cnt.value
+        t = np.ctypeslib.as_array(tags, shape=(n,)).copy()
+        i = np.ctypeslib.as_array(idx, shape=(c,)).copy() if c else np.zeros(0, np.uint32)
+        v = np.ctypeslib.as_array(vals, shape=(c, 4)).copy() if c else np.zeros((0, 4), np.uint64)
+        return t, i, v
 
     def is_satisfied(self):
         return bool(lib().zkg_circuit_is_satisfied(self._h))

@@ -34,7 +34,8 @@ struct Constraint { Span a, b, c; };
 
 struct Builder {
     std::vector<Fr> val;                 // val[0] == 1
-    std::vector<uint8_t> nz;             // nz[v] = (val[v] != 0): what the boolean gadgets read on the witness path
+    std::vector<uint8_t> nz;             // nz[v]: 0 = zero, 1 = exactly one, 2 = any other value.  The boolean gadgets read it as
+                                         // "non-zero" on the witness path; the prover's sparse upload reads it as a tag.
     std::vector<Constraint> cons;
     std::vector<std::pair<Var, Fr>> arena;
     uint32_t num_inputs = 0;
@@ -57,7 +58,7 @@ struct Builder {
         if (root) return cursor < cursor_end ? cursor++ : (cursor++, 0);     // overrun is detected by the caller (cursor > cursor_end)
         val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1);
     }
-    void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = !x.is_zero(); }
+    void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = x.is_zero() ? 0 : (x == Fr::one() ? 1 : 2); }
     void set_bit(Var v, bool b) { Builder &r = root ? *root : *this; r.val[v] = b ? Fr::one() : Fr::zero(); r.nz[v] = b; }
     bool is_nonzero(Var v) const { return (root ? root : this)->nz[v] != 0; }
     std::vector<Var> alloc_n(size_t n) {

@@ -58,6 +58,7 @@ struct zkg_circuit {
     Builder pb;
     Builder::Csr A, B, C;
     bool has_witness = false;
+    bool sparse_built = false; std::vector<uint32_t> full_index; std::vector<uint64_t> full_values;
 };
 
 // The variable storage of a finished circuit (18 MB at 20 payloads) is handed to the next one: a prover calls this once per proof,
@@ -250,6 +251,21 @@ int zkg_circuit_r1cs(const zkg_circuit *c, zkg_r1cs *out) {
 const uint64_t *zkg_circuit_witness(const zkg_circuit *c) {
     static_assert(sizeof(Fr) == 32, "Fr must be the ABI's 32-byte element");
     return (c && c->has_witness) ? reinterpret_cast<const uint64_t *>(c->pb.val.data() + 1) : nullptr;
+}
+// sparse form of the same witness for zkg_groth16_prove_sparse: one tag per variable (0 zero, 1 one, 2 listed) and the listed variables.
+// The lists live in the circuit object and are built on the first call.
+int zkg_circuit_sparse_witness(const zkg_circuit *c_, const uint8_t **tags, const uint32_t **full_index, const uint64_t **full_values, size_t *count) {
+    zkg_circuit *c = const_cast<zkg_circuit *>(c_);
+    if (!c || !c->has_witness || !tags || !full_index || !full_values || !count) return ZKG_ERROR;
+    const uint32_t n = c->pb.num_variables();
+    if (!c->sparse_built) {
+        c->full_index.clear(); c->full_values.clear();
+        const uint8_t *t = c->pb.nz.data() + 1;
+        for (uint32_t v = 0; v < n; ++v) if (t[v] == 2) { c->full_index.push_back(v); const uint32_t *w = c->pb.val[v + 1].v; uint64_t l4[4]; memcpy(l4, w, 32); c->full_values.insert(c->full_values.end(), l4, l4 + 4); }
+        c->sparse_built = true;
+    }
+    *tags = c->pb.nz.data() + 1; *full_index = c->full_index.data(); *full_values = c->full_values.data(); *count = c->full_index.size();
+    return ZKG_OK;
 }
 int zkg_circuit_is_satisfied(const zkg_circuit *c) { return c && c->has_witness && c->pb.recording && c->pb.is_satisfied() ? 1 : 0; }
 uint32_t zkg_circuit_num_variables(const zkg_circuit *c) { return c ? c->pb.num_variables() : 0; }
