@@ -28,6 +28,22 @@ G1_GEN_MONT = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f787946
                         0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
 
 
+def kernel_source_sha16():
+    """sha256[:16] over the HIP sources the dominant kernel is built from: profiles/pmc_traffic.json records the value it was collected
+    on (tools/pmc_summary.py), and the traffic figure is only reported when it still matches the sources this run was built from"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("msm.hip", "curve.hip.hpp", "fp.hip.hpp", "mont_asm.inc"):
+        with open(os.path.join(ROOT, "zklaim_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def stats_ms(samples):
+    a = np.sort(np.asarray(samples, dtype=np.float64)) * 1e3
+    return {"median": round(float(np.median(a)), 4), "min": round(float(a[0]), 4), "max": round(float(a[-1]), 4), "n": int(a.size)}
+
+
 def splitmix_fr(n, seed):
     """n uniform canonical scalars in [0, r): SplitMix64 stream, 4 draws -> 254 bits -> rejection."""
     out = np.zeros((0, 4), np.uint64)
@@ -73,19 +89,37 @@ def extras(zkg, torch, args, with_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (2 * reps)
     roundtrip_ok = bool(np.array_equal(d_a.cpu().numpy().view(np.uint64), a))
-    out["ntt_2p20"] = {"ms_per_transform": round(dt * 1e3, 4), "GBps_algorithmic": round(64 * n / dt / 1e9, 2), "bytes_per_element": 64,
-                       "frac_of_hbm_peak": round(64 * n / dt / 1e9 / HBM_PEAK_GBPS, 5), "forward_inverse_roundtrip_exact": roundtrip_ok}
+    # device time of one transform, HIP events on the launch stream (back-to-back launches, no host gaps)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        zkg.ntt_dev(d_a.data_ptr(), logn, inverse=False, stream=torch.cuda.current_stream().cuda_stream)
+    ev[1].record(); torch.cuda.synchronize()
+    dev_ms = ev[0].elapsed_time(ev[1]) / reps
+    out["ntt_2p20"] = {"ms_per_transform": round(dt * 1e3, 4), "device_ms_per_transform": round(dev_ms, 4), "GBps_algorithmic": round(64 * n / dt / 1e9, 2),
+                       "GBps_algorithmic_device": round(64 * n / (dev_ms * 1e-3) / 1e9, 2), "bytes_per_element": 64,
+                       "frac_of_hbm_peak": round(64 * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "forward_inverse_roundtrip_exact": roundtrip_ok}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import zkoracle
+        t1 = time.perf_counter()
+        ref = zkoracle.fft(a, inverse=False)
+        cpu_dt = time.perf_counter() - t1
+        zkg.ntt_dev(d_a.data_ptr(), logn, inverse=False); torch.cuda.synchronize()
+        out["ntt_2p20"]["cpu_baseline"] = {"seconds": round(cpu_dt, 3), "cores": 1, "kind": "port", "sample": "one forward 2^20 transform, oracle serial radix-2 FFT",
+                                          "gpu_matches_cpu": bool(np.array_equal(d_a.cpu().numpy().view(np.uint64), ref))}
 
-    out["groth16_prove"] = prove_leg(zkg, torch, args, with_cpu)
+    out["groth16_prove"] = prove_leg(zkg, torch, args, with_cpu, args.prove_logm)
+    if args.prove_logm != 20 and not args.no_northstar:
+        out["groth16_prove_2p20"] = prove_leg(zkg, torch, args, with_cpu, 20)                # the north star's 2^20-constraint case
     return out
 
 
-def prove_leg(zkg, torch, args, with_cpu):
+def prove_leg(zkg, torch, args, with_cpu, logm):
     # ---- Groth16 prove on zklaim's own credential circuit (zklaim_gadget rebuilt on the host, zklaim_amd/csrc/zklaim_circuit.hip):
     #      k payloads -> m = 2^logm (k = 8 -> 2^18, BASELINE configs[3]; k = 20 -> 2^20, the north-star size).  Keys come from the
     #      product's GPU generator with a fixed trapdoor; (r, s) fixed; the CPU oracle proves the same instance for byte parity.
-    logm = args.prove_logm
-    k_payloads = {15: 1, 16: 2, 17: 4, 18: 8, 19: 16, 20: 38}.get(logm, 8)      # 38 payloads: C + l + 1 = 1 047 968 -> m = 2^20
+    k_payloads = {15: 1, 16: 2, 17: 4, 18: 8, 19: 16, 20: 37}.get(logm, 8)      # 37 payloads: C + l + 1 = 1 023 318 -> m = 2^20
     t_syn = time.perf_counter()
     keep = []
     pls = [dict(attrs=[1990 + i, 7 * i, 42, i, 5], refs=[2100, 7 * i, 41, 0, 5], ops=["less", "eq", "greater", "noop", "greater_or_eq"], salt=0x5A4B + i)
@@ -105,23 +139,28 @@ def prove_leg(zkg, torch, args, with_cpu):
         rc, proof = crs.prove(w, rs[0], rs[1])
     assert rc == 0, "credential must satisfy the circuit"
     verified = zkg.groth16_verify(kp.vk_blob(), w[:l], proof) == 0
-    reps = 10
-    t0 = time.perf_counter()
+    reps = 30                                                     # the reference's benchmark protocol: RUNS = 30 (src/main_benchmark.c:175-176)
+    each = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         rc, proof2 = crs.prove(w, rs[0], rs[1])
-    dt = (time.perf_counter() - t0) / reps
+        each.append(time.perf_counter() - t0)
+    dt = sum(each) / reps
     tags, fidx, fvals = ck.sparse_witness()                      # the seam's form of the same witness: tags + the ~3 % non-bit values
     rc_s, proof_s = crs.prove_sparse(tags, fidx, fvals, rs[0], rs[1])
-    t0 = time.perf_counter()
+    each_sparse = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         crs.prove_sparse(tags, fidx, fvals, rs[0], rs[1])
-    dt_sparse = (time.perf_counter() - t0) / reps
+        each_sparse.append(time.perf_counter() - t0)
+    dt_sparse = sum(each_sparse) / reps
     A, B, C = ck.csr()
     nnz = int(len(A[1]) + len(B[1]) + len(C[1]))
     alg_bytes = 7 * 64 * m + 96 * (nv + 1) + (128 + 64 + 32) * (nv + 1) + 96 * (m - 1) + 96 * (nv - l)
     g = {"circuit": f"zklaim_gadget, {k_payloads} payloads (SHA-256 + 5 comparisons each)", "log_m": logm, "domain_size": int(m), "num_variables": int(nv), "num_inputs": int(l),
          "num_constraints": int(ncons), "nnz": nnz, "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3),
-         "ms_per_proof_sparse_witness": round(dt_sparse * 1e3, 3), "sparse_witness_same_bytes": bool(rc_s == 0 and proof_s == proof),
+         "ms_per_proof_stats": stats_ms(each), "ms_per_proof_sparse_witness": round(dt_sparse * 1e3, 3), "ms_per_proof_sparse_witness_stats": stats_ms(each_sparse),
+         "timing_note": "wall clock around the C-ABI call: witness H2D (dense: 32 B per variable; sparse: tags + listed values), all device work, proof D2H, host assembly", "sparse_witness_same_bytes": bool(rc_s == 0 and proof_s == proof),
          "algorithmic_bytes_per_proof": int(alg_bytes), "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
          "stage_names": ["r1cs_matvec", "7_ntt+pointwise", "msm_A", "msm_B_g1", "msm_B_g2", "msm_H", "msm_L", "wall_total_incl_host_assembly"],
          "stage_note": "the five MSMs run concurrently on separate HIP streams; their times overlap",
@@ -144,6 +183,7 @@ def prove_leg(zkg, torch, args, with_cpu):
                              "sample": "one full prove of the same credential, oracle restatement of r1cs_gg_ppzksnark_prover, single thread"}
         g["proof_bytes_match_cpu"] = bool(rc_o == 0 and proof_o == proof)
         g["speedup_vs_cpu_1core"] = round(cpu_dt / dt, 1)
+        g["speedup_note"] = "against the single-thread PORT (oracle restatement), not libsnark's own x86-64 assembly build; a ratio says nothing about kernel quality"
     crs.free(); kp.free(); ck.free()
     return g
 
@@ -159,7 +199,8 @@ def main():
                          "and owns every N-th Pippenger window; SURVEY.md section 8e's variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
-    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 38 payloads (the north star's 2^20-constraint case)")
+    ap.add_argument("--no-northstar", action="store_true", help="skip the second prove leg (37 payloads, m = 2^20: the north star's 2^20-constraint case)")
+    ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 37 payloads (the north star's 2^20-constraint case)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print banners (RCCL prints its version on first use) go to stderr
@@ -219,9 +260,12 @@ def main():
         result = step()
     fence()
     zkg.timing_reset()
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = step()
+        t_s = time.perf_counter()
+        result = step()                                   # returns after the result point is on the host (the call synchronises its stream)
+        per_step.append(time.perf_counter() - t_s)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -229,6 +273,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches = zkg.timing_dominant_ms()
+    # SURVEY.md section 8(d)'s other form of the same step: the scalars start in (pinned) HOST memory and their 32 B x n upload is inside the timed
+    # call, bases resident.  Reported next to `value`, never as `value`.
+    h2d = None
+    if world == 1:
+        h_sc = torch.from_numpy(sc.view(np.int64)).pin_memory()
+        d_sc2 = torch.empty_like(d_sc)
+        def step_h2d():
+            d_sc2.copy_(h_sc, non_blocking=True)
+            return zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n, stream=stream)
+        step_h2d(); step_h2d()
+        each = []
+        for _ in range(args.steps):
+            t_s = time.perf_counter(); r2 = step_h2d(); each.append(time.perf_counter() - t_s)
+        h2d = {"ms_per_step": stats_ms(each), "GBps_algorithmic_median": round(BYTES_PER_POINT * n / float(np.median(each)) / 1e9, 3),
+               "same_result": bool(np.array_equal(r2, result)), "what": "scalar H2D (32 B x points from pinned host memory) + MSM + result D2H inside the timed call; bases resident"}
 
     total_points = n if by_windows else n * world
     n = n // world if by_windows else n            # per-rank share of the points, for the per-launch algorithmic bytes below
@@ -238,7 +297,8 @@ def main():
 
     line = {
         "metric": "Groth16 proofs/sec (zklaim gadget, alt_bn128) + G1 MSM GB/s vs HBM roofline", "metric_component": "G1 MSM GB/s (value, unit); Groth16 proofs/sec of the zklaim gadget in extras.groth16_prove and proofs_per_sec", "value": round(value, 3), "unit": "GB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_stats": stats_ms(per_step),
+        "incl_scalar_h2d": h2d, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32x8-montgomery (254-bit Fq/Fr)", "data": "synthetic",
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
@@ -269,10 +329,13 @@ def main():
     if args.logn == LOGN and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            line["roofline"]["traffic"] = pmc.get("dominant_hbm_bytes_per_launch")
-            line["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x gather calibration + WRITE_SIZE, separate --pmc passes)"
             line["roofline"]["algorithmic_bytes_per_launch"] = BYTES_PER_POINT * n
-            line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+            if pmc.get("source_sha16") == kernel_source_sha16():
+                line["roofline"]["traffic"] = pmc.get("dominant_hbm_bytes_per_launch")
+                line["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x gather calibration + WRITE_SIZE, separate --pmc passes)"
+                line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (collected on these kernel sources: sha16 " + pmc["source_sha16"] + ")"
+            else:
+                line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json was collected on other kernel sources; not reported (re-run tools/pmc_collect.sh)"
         except Exception:
             pass
 

@@ -38,8 +38,11 @@ extern "C" {
 
 #define ZKG_OK 0
 #define ZKG_ERROR 1          /* generic failure (bad argument, HIP error)            */
-#define ZKG_UNSATISFIED 1    /* libsnark_prove returns 1 on an unsatisfied system
-                                (zklaim/libsnark_wrapper.cpp:233-240)                */
+#define ZKG_UNSATISFIED 2    /* zkg_groth16_prove*: the witness violates the constraint
+                                system and no proof was made.  A code of its own, so that
+                                callers never have to tell it from ZKG_ERROR by the error
+                                text; the seam maps it to the reference's return value 1
+                                (libsnark_prove, zklaim/libsnark_wrapper.cpp:233-240)   */
 #define ZKG_PROOF_BYTES 134  /* G1(34) || G2(66) || G1(34), see zkg_groth16_prove    */
 
 /* ---- R1CS in CSR form (three matrices).  Column 0 is the constant ONE, columns
@@ -152,9 +155,11 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk);
 /* Same, from the byte blob zklaim keeps in ctx->pk (written by libsnark_export_pk, libsnark_wrapper.cpp:146-157, i.e.
  * operator<<(r1cs_gg_ppzksnark_proving_key) under libsnark's default flags: binary, Montgomery, compressed points).
  * Replaces libsnark_import_pk (libsnark_wrapper.cpp:160-168); the ~4n+m point decompressions (one square root each) run
- * on the GPU.  Only basic_radix2 domains (|H_query| + 1 a power of two).                                             */
+ * on the GPU.  The domain is recovered from |H_query| + 1 (2^k, or a step_radix2 size 2^a + 2^b).  Counts inside the blob are
+ * bounded by the bytes that follow them before anything is sized by them: a malformed blob is an error return, never a fault. */
 zkg_crs *zkg_crs_upload_blob(const void *pk_blob, size_t len);
 void     zkg_crs_free(zkg_crs *crs);
+uint32_t zkg_crs_num_variables(const zkg_crs *crs);   /* n of the resident key (the witness length zkg_groth16_prove expects) */
 
 /* ---- Groth16 prove: r1cs_gg_ppzksnark_prover (snark.cpp:126) with the prover
  *      randomness (r, s) as explicit inputs (libsnark draws them internally).
@@ -184,7 +189,13 @@ int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
  *      zklaim_input_map (zklaim_gadget.cpp:115-150).  `ctx` is zklaim's own zklaim_ctx (include/zklaim_abi.h).           */
 struct zklaim_ctx;
 typedef struct zkg_circuit zkg_circuit;
-zkg_circuit *zkg_zklaim_circuit_new(const struct zklaim_ctx *ctx, int with_witness);
+/* flags: ZKG_CIRCUIT_WITH_WITNESS assigns the variables from ctx (generate_r1cs_witness);
+ *        ZKG_CIRCUIT_REFERENCE_QUIRK leaves the pack_PL / pack_REF / pack_OPS packings unconstrained as the reference does
+ *        (zklaim_gadget.cpp:583-699 never generates them): refvals / opsvals / plvars are then free witness variables and the
+ *        proof only binds SHA256(pre) == hash.  Default (flag clear): the packings are enforced (78 constraints per payload). */
+#define ZKG_CIRCUIT_WITH_WITNESS 1
+#define ZKG_CIRCUIT_REFERENCE_QUIRK 2
+zkg_circuit *zkg_zklaim_circuit_new(const struct zklaim_ctx *ctx, int flags);
 zkg_circuit *zkg_zklaim_witness_new(const struct zklaim_ctx *ctx);   /* witness only: no constraints, no CSR (prover with a resident key) */
 uint32_t zkg_circuit_num_variables(const zkg_circuit *c);
 void zkg_circuit_free(zkg_circuit *c);
@@ -220,6 +231,13 @@ int libsnark_trusted_setup(struct zklaim_ctx *ctx);
 int libsnark_prove(struct zklaim_ctx *ctx);
 int libsnark_verify(struct zklaim_ctx *ctx);
 void zkg_compat_reset(void);
+
+/* ---- known-answer hook for the device arithmetic (libff Fp_model<4,...>::mul_reduce, Fp2_model —
+ *      here the generated v_mad_u64_u32 streams of csrc/mont_asm.inc).  Element-wise ON THE GPU, host pointers:
+ *      field 0 = Fq, 1 = Fr (4 limbs per element), 2 = Fq2 (8 limbs);  op 0 mul, 1 add, 2 sub, 3 inverse, 4 to Montgomery form,
+ *      5 from Montgomery form, 6 negate, 7 square (4 and 5: Fq / Fr only).  Inputs and outputs are Montgomery limbs except op 4's
+ *      input and op 5's output (canonical); outputs are fully reduced.  b is read by ops 0-2 only.                                */
+int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
  * average device ms per launch of the dominant kernel over the calls since the last reset */

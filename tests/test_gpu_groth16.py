@@ -25,7 +25,7 @@ def test_prove_golden(zkg, case):
     assert rc == 0 and proof2 == proof
     bad = w.copy(); bad[-1, 0] ^= np.uint64(1)
     rc, _ = crs.prove(bad, r, s)
-    assert rc == 1                                   # libsnark_prove: "system not satisfied" -> 1
+    assert rc == zkg.UNSATISFIED                     # libsnark_prove maps this to its return value 1
     crs.free()
 
 
@@ -120,7 +120,7 @@ def test_prove_real_zklaim_circuit(zkg, oracle):
     bad = dict(pl); bad["ops"] = ["greater", "eq", "greater", "noop", "noop"]           # 1994 > 2000 is false
     wbad = zkg.ZklaimCircuit(zkg.make_ctx([bad], keep)).witness()
     rc, _ = crs.prove(wbad, rs[0], rs[1])
-    assert rc == 1
+    assert rc == zkg.UNSATISFIED
     crs.free()
 
 
@@ -145,7 +145,7 @@ def test_prove_sparse_witness_matches_dense(zkg):
     assert zkg.groth16_verify(kp.vk_blob(), w[:ck.r1cs.num_inputs], sparse) == 0
     bad = tags.copy(); k = int(np.flatnonzero(tags == 1)[-1]); bad[k] = 0
     rc3, _ = crs.prove_sparse(bad, idx, vals, rs[0], rs[1])
-    assert rc3 == 1
+    assert rc3 == zkg.UNSATISFIED
     rc4, again = crs.prove(w, rs[0], rs[1])
     assert rc4 == 0 and again == dense
     crs.free(); kp.free()

@@ -71,7 +71,7 @@ def test_prove_golden_step(zkg, case):
     assert rc == 0 and proof.hex() == case["proof_hex"]
     bad = w.copy(); bad[-1, 0] ^= np.uint64(1)
     rc, _ = crs.prove(bad, r, s)
-    assert rc == 1
+    assert rc == zkg.UNSATISFIED
     crs.free()
     # a pk that claims the next power of two for a system stored with step-domain queries is inconsistent: H_query is too short
     # for it, and the ABI has no way to see that, so the honest failure mode is a size mismatch on the blob path (below)

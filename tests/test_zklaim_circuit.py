@@ -112,4 +112,55 @@ print(h.hexdigest(), ck.r1cs.num_constraints, ck.r1cs.num_variables)
         if serial:
             env["ZKG_SERIAL_CIRCUIT"] = "1"
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] and outs[0].split()[1] == str(3 * 27573 + 2), outs
+    assert outs[0] == outs[1] and outs[0].split()[1] == str(3 * 27651 + 2), outs
+
+
+def _var_layout(k):
+    """0-based witness positions of the value variables, in the allocation order of build_zklaim (zklaim_circuit.hip; the reference's
+    constructor order, zklaim_gadget.cpp:348-540): inputs, zero, (data, less, less_or_eq) x 5 per payload, plvars, refvals, opsvals"""
+    n_inputs = -(-1280 * k // 253)
+    base = n_inputs + 1
+    data = lambda i, j: base + 3 * (5 * i + j)
+    pl0 = base + 15 * k
+    return dict(data=data, plvars=lambda c: pl0 + c, refvals=lambda c: pl0 + 6 * k + c, opsvals=lambda c: pl0 + 14 * k + c)
+
+
+def test_malicious_prover_cannot_rebind_values(oracle):
+    """The reference never generates the pack_PL / pack_REF / pack_OPS constraints (zklaim_gadget.cpp:583-699), which leaves the op
+    one-hot, the reference values and the compared attributes free: a prover who knows the pre-image satisfies ANY public predicate.
+    The default circuit here enforces the packings; ZKG_CIRCUIT_REFERENCE_QUIRK reproduces the reference's shape.  An honest
+    witness for the false claim 1994 > 2000 is patched the way a cheating prover would, and checked on both systems."""
+    from util import R, arr
+    keep = []
+    honest = payload(["less", "noop", "noop", "noop", "noop"], [2000, 0, 0, 0, 0])
+    claim = payload(["greater", "noop", "noop", "noop", "noop"], [2000, 0, 0, 0, 0])                  # 1994 > 2000: false
+    lay = _var_layout(1)
+    one, zero = arr([1], R)[0], arr([0], R)[0]
+    systems = {}
+    for quirk in (False, True):
+        ck = zkg.ZklaimCircuit(zkg.make_ctx([claim], keep), reference_quirk=quirk)
+        assert not ck.is_satisfied()                                                                  # the honest witness generator refuses
+        A, B, Cm = ck.csr()
+        systems[quirk] = (oracle.make_r1cs(ck.r1cs.num_variables, ck.r1cs.num_inputs, A, B, Cm, keep), ck.witness(), ck.r1cs.num_constraints)
+    assert systems[False][2] == systems[True][2] + 78 and np.array_equal(systems[False][1], systems[True][1])     # same witness, 6 + 8 + 64 more rows
+    w = systems[False][1]
+    assert np.array_equal(w[lay["data"](0, 0)], arr([1994], R)[0]) and np.array_equal(w[lay["refvals"](0)], arr([2000], R)[0])
+    assert np.array_equal(w[lay["opsvals"](4)], one) and np.array_equal(w[lay["plvars"](0)], arr([1994], R)[0])
+    # attack 1: flip the private copy of the op one-hot to noop (public ops bits still say "greater")
+    forged = w.copy(); forged[lay["opsvals"](4)] = zero; forged[lay["opsvals"](6)] = one
+    assert oracle.r1cs_is_satisfied(systems[True][0], forged), "the reference's shape accepts the forged one-hot (that is the quirk)"
+    assert not oracle.r1cs_is_satisfied(systems[False][0], forged)
+    # attack 2: compare against a different reference value than the public one.  Rebuild the comparison's witness by asking the
+    # generator for the same attributes against ref 1000 (1994 > 1000 holds) and keep the PUBLIC input of the false claim.
+    other = zkg.ZklaimCircuit(zkg.make_ctx([payload(["greater", "noop", "noop", "noop", "noop"], [1000, 0, 0, 0, 0])], keep), reference_quirk=True)
+    assert other.is_satisfied()
+    forged2 = other.witness().copy()
+    l = other.r1cs.num_inputs
+    first_bit = 6 + 1 + 15 + 6 + 8 + 64                                                              # h_bits | ref_bits | ops_bits follow the value variables
+    forged2[:l] = w[:l]; forged2[first_bit:first_bit + 1280] = w[first_bit:first_bit + 1280]          # public values and their bits: the false claim's
+    assert oracle.r1cs_is_satisfied(systems[True][0], forged2), "the reference's shape lets refvals differ from the public reference bits"
+    assert not oracle.r1cs_is_satisfied(systems[False][0], forged2)
+    # the honest statement is accepted by both
+    for quirk in (False, True):
+        ck = zkg.ZklaimCircuit(zkg.make_ctx([honest], keep), reference_quirk=quirk)
+        assert ck.is_satisfied()

@@ -2,7 +2,7 @@
 // independent chains in one wavefront (does a lone wavefront reach the VALU issue rate?).  hipcc --offload-arch=gfx950 -O3 -std=c++17
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../zklaim_amd/csrc/fp.cuh"
+#include "../zklaim_amd/csrc/fp.hip.hpp"
 using namespace zk;
 __global__ __launch_bounds__(256) void k_chain1(Fq *io, int iters) {
     Fq x = io[threadIdx.x], y = io[threadIdx.x + 256];

@@ -46,5 +46,9 @@ if acc:
     e["hbm_bytes_corrected"] = int(e["fetch_bytes_raw"] * gather_factor + e["write_bytes_raw"] * store_factor)
     out["dominant_kernel"] = k
     out["dominant_hbm_bytes_per_launch"] = e["hbm_bytes_corrected"]
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_sha16
+out["source_sha16"] = kernel_source_sha16()          # bench.py reports the traffic figure only while the kernel sources still hash to this
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])

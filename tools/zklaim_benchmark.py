@@ -4,14 +4,19 @@ pk / vk / proof sizes — same CSV columns as the reference writes (main_benchma
 reference's CLOCK_THREAD_CPUTIME_ID (main_benchmark.c:113-117) does not see time spent waiting on the GPU.
 prover_ms is the mean of 5 libsnark_prove calls on the resident key after 3 warm-up calls (the first calls on a new key grow the
 runtime's per-stream pools); first_prove_ms is the very first call, which parses the pk blob, decompresses it on the GPU and uploads.
-Usage: python tools/zklaim_benchmark.py [k ...]   (default 1..20 as main_benchmark.c:175-182; RUNS=2 instead of the reference's 30)."""
+Usage: python tools/zklaim_benchmark.py [k ...]   (default 1..20 payloads and --runs 30, as main_benchmark.c:175-182)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import zklaim_amd as zkg
 
-ks = [int(x) for x in sys.argv[1:]] or list(range(1, 21))
-RUNS = 2
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("ks", nargs="*", type=int)
+ap.add_argument("--runs", type=int, default=30, help="repetitions per payload count (the reference: RUNS 30, main_benchmark.c:175-176)")
+cli = ap.parse_args()
+ks = cli.ks or list(range(1, 21))
+RUNS = cli.runs
 zkg.init(0)
 print("time,k,issuer_ms,prover_ms,verifier_ms,pk_B,vk_B,proof_B,constraints,first_prove_ms_incl_key_upload,domain_m,domain_kind")
 for k in ks:

@@ -16,14 +16,17 @@ _SO = os.path.join(_HERE, "libzkg.so")
 DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_evaluation_domain_size", "zkg_ntt_domain", "zkg_ntt_domain_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_msm_g1_windows_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
-    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_groth16_prove", "zkg_groth16_prove_sparse", "zkg_circuit_sparse_witness", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
+    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_crs_num_variables", "zkg_groth16_prove", "zkg_groth16_prove_sparse", "zkg_circuit_sparse_witness", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
-    "zkg_compat_reset",
+    "zkg_compat_reset", "zkg_field_op",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
+
+
+OK, ERROR, UNSATISFIED = 0, 1, 2          # include/zkg.h
 
 
 class ZkgError(RuntimeError):
@@ -105,6 +108,15 @@ def device_info():
     name = C.create_string_buffer(128); cus = C.c_int(0)
     _check(lib().zkg_device_info(name, C.c_size_t(128), C.byref(cus)), "zkg_device_info")
     return name.value.decode(), cus.value
+
+
+def field_op(field, op, a, b=None):
+    """element-wise device arithmetic (zkg_field_op): field 0 Fq, 1 Fr, 2 Fq2; op 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr"""
+    a = _u64(a); limbs = 8 if field == 2 else 4
+    out = np.zeros_like(a)
+    bb = None if b is None else _u64(b)
+    _check(lib().zkg_field_op(int(field), int(op), _p(a), _p(bb), C.c_size_t(a.size // limbs), _p(out)), "zkg_field_op")
+    return out
 
 
 # ---- NTT (libfqfft basic_radix2_domain FFT/iFFT/cosetFFT/icosetFFT) -------------------------------
@@ -239,10 +251,10 @@ class Crs:
             raise ZkgError("zkg_crs_upload failed: " + lib().zkg_last_error().decode())
 
     def prove(self, witness, r, s, check_satisfied=True):
-        """-> (rc, proof bytes); rc == 1 reproduces libsnark_prove's 'system not satisfied' return."""
+        """-> (rc, proof bytes); rc == UNSATISFIED (2): the gate of snark.cpp:121-124 refused the witness (libsnark_prove returns 1 there)."""
         out = np.zeros(256, np.uint8); ln = C.c_size_t(0)
         rc = lib().zkg_groth16_prove(C.c_void_p(self._h), _p(_u64(witness)), _p(_u64(r)), _p(_u64(s)), int(check_satisfied), _p(out), C.byref(ln))
-        if rc not in (0, 1):
+        if rc not in (OK, UNSATISFIED):
             _check(rc, "zkg_groth16_prove")
         return rc, bytes(out[:ln.value])
 
@@ -252,7 +264,7 @@ class Crs:
         out = np.zeros(256, np.uint8); ln = C.c_size_t(0)
         rc = lib().zkg_groth16_prove_sparse(C.c_void_p(self._h), _p(tags), _p(full_index), _p(full_values), C.c_size_t(full_index.size), _p(_u64(r)), _p(_u64(s)),
                                             int(check_satisfied), _p(out), C.byref(ln))
-        if rc not in (0, 1):
+        if rc not in (OK, UNSATISFIED):
             _check(rc, "zkg_groth16_prove_sparse")
         return rc, bytes(out[:ln.value])
 
@@ -329,7 +341,7 @@ def make_ctx(payloads, keep):
 class ZklaimCircuit:
     """R1CS (+ witness) of zklaim_gadget for a zklaim_ctx, built on the host by libzkg.so"""
 
-    def __init__(self, ctx, with_witness=True, witness_only=False):
+    def __init__(self, ctx, with_witness=True, witness_only=False, reference_quirk=False):
         L = lib()
         L.zkg_zklaim_circuit_new.restype = C.c_void_p
         L.zkg_zklaim_circuit_new.argtypes = [C.c_void_p, C.c_int]
@@ -345,7 +357,7 @@ class ZklaimCircuit:
         if witness_only:
             self._h = L.zkg_zklaim_witness_new(C.cast(C.pointer(ctx), C.c_void_p))
         else:
-            self._h = L.zkg_zklaim_circuit_new(C.cast(C.pointer(ctx), C.c_void_p), int(with_witness))
+            self._h = L.zkg_zklaim_circuit_new(C.cast(C.pointer(ctx), C.c_void_p), (1 if with_witness else 0) | (2 if reference_quirk else 0))
         if not self._h:
             raise ZkgError("zkg_zklaim_circuit_new failed: " + L.zkg_last_error().decode())
         self.r1cs = R1CS()

@@ -139,6 +139,38 @@ G2 load_norm_g2(const uint64_t *in) {
     return {{get(in), get(in + 4)}, {get(in + 8), get(in + 12)}, Fq2::one(), Fq2::one()};
 }
 
+// ---- device field arithmetic, element-wise (the known-answer hook behind zkg_field_op) ---------------------------
+template <class F> ZK_D F field_apply(int op, const F &x, const F &y) {
+    switch (op) {
+    case 0: return x * y;   case 1: return x + y;   case 2: return x - y;   case 3: return x.inverse();
+    case 6: return x.neg(); case 7: return x.sqr();
+    default: return x;
+    }
+}
+template <class F> __global__ __launch_bounds__(64) void k_field_op(int op, const F *a, const F *b, size_t n, F *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = a[i], y = b ? b[i] : x;
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        if (op == 4) { out[i] = x.to_mont().normalized(); return; }
+        if (op == 5) { out[i] = x.from_mont(); return; }
+    }
+    out[i] = field_apply(op, x, y).normalized();
+}
+template <class F> static int field_op_run(int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
+    DevBuf da, db, dout;
+    const size_t bytes = n * sizeof(F);
+    int rc = ZKG_ERROR;
+    if (!da.reserve(bytes) && !dout.reserve(bytes) && (!b || !db.reserve(bytes)) &&
+        hip_ok(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) &&
+        (!b || hip_ok(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__))) {
+        hipLaunchKernelGGL(k_field_op<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, op, da.as<F>(), b ? db.as<F>() : (const F *)nullptr, n, dout.as<F>());
+        if (hipGetLastError() == hipSuccess && hip_ok(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) rc = ZKG_OK;
+    }
+    da.release(); db.release(); dout.release();
+    return rc;
+}
+
 static std::mutex g_init_mu;
 static int g_device = -1;
 static void kernels_configure() { (void)ntt_configure(); (void)msm_configure(); }
@@ -302,6 +334,16 @@ int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t
     REQUIRE_INIT();
     G2Affine b; memcpy(&b, base, 128);
     return fixed_base_g2(b, (const uint32_t *)d_scalars, n, (G2Affine *)d_out_affine, (hipStream_t)stream);
+}
+
+int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
+    REQUIRE_INIT();
+    const bool binary = op >= 0 && op <= 2, known = binary || op == 3 || op == 6 || op == 7 || ((op == 4 || op == 5) && field != 2);
+    if (!known || field < 0 || field > 2 || !a || !out || (binary && !b)) { set_error("zkg_field_op: bad argument"); return ZKG_ERROR; }
+    if (!n) return ZKG_OK;
+    if (field == 0) return field_op_run<Fq>(op, a, binary ? b : nullptr, n, out);
+    if (field == 1) return field_op_run<Fr>(op, a, binary ? b : nullptr, n, out);
+    return field_op_run<Fq2>(op, a, binary ? b : nullptr, n, out);
 }
 
 void zkg_timing_reset(void) { g_dominant_timer.reset(); }

@@ -101,6 +101,16 @@ struct Reader {
         return v;
     }
     const uint8_t *take(size_t n) { if (!ok || (size_t)(end - p) < n) { ok = false; return nullptr; } const uint8_t *r = p; p += n; return r; }
+    // a record count: refused unless `count` records of `record_bytes` each can still follow in the blob and count < 2^31, so that no
+    // later product (count * stride, count * limbs, count * sizeof) can wrap and no 32-bit cast can truncate.  The blob comes from the
+    // issuer (ctx->pk), i.e. it is not trusted input to the holder's prover.
+    size_t count(size_t record_bytes) {
+        size_t v = decimal();
+        if (!ok) return 0;
+        if (v >= ((size_t)1 << 31) || (record_bytes && v > (size_t)(end - p) / record_bytes)) { ok = false; return 0; }
+        return v;
+    }
+    const uint8_t *take_records(size_t n, size_t record_bytes) { return take(n * record_bytes); }       // n came from count(record_bytes): no overflow
 };
 
 template <class A, class K>
@@ -122,7 +132,7 @@ static int decompress(K kernel, const uint8_t *host_rec, size_t stride, size_t o
 
 using namespace zk;
 
-extern "C" zkg_crs *zkg_crs_upload_blob(const void *blob, size_t len) {
+static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     if (!blob || len < 34 * 3 + 66 * 2) { set_error("zkg_crs_upload_blob: blob too short"); return nullptr; }
     Reader rd{(const uint8_t *)blob, (const uint8_t *)blob + len};
     DevBuf d_rec, d_out, d_flag;
@@ -137,35 +147,35 @@ extern "C" zkg_crs *zkg_crs_upload_blob(const void *blob, size_t len) {
     if (decompress<G1Affine>(k_decompress_g1, head1, 34, 0, 3, small1, 8, d_rec, d_out, d_flag) ||
         decompress<G2Affine>(k_decompress_g2, head2, 66, 0, 2, small2, 16, d_rec, d_out, d_flag)) return fail(nullptr);
     // A_query
-    size_t nA = rd.decimal(); const uint8_t *recA = rd.take(nA * 34);
+    size_t nA = rd.count(34); const uint8_t *recA = rd.take_records(nA, 34);
     if (!rd.ok || nA == 0) return fail("pk blob: bad A_query");
     std::vector<uint64_t> A_query, H_query, L_query, Bv_g2, Bv_g1;
     if (decompress<G1Affine>(k_decompress_g1, recA, 34, 0, nA, A_query, 8, d_rec, d_out, d_flag)) return fail(nullptr);
     // B_query (sparse knowledge commitments: G2 then G1 per value)
-    size_t domain = rd.decimal(), nidx = rd.decimal();
+    size_t domain = rd.count(0), nidx = rd.count(2);                      // an index is at least one digit and a newline
     if (!rd.ok || domain != nA || nidx > domain) return fail("pk blob: bad B_query header");
     std::vector<size_t> idx(nidx);
     for (size_t i = 0; i < nidx; ++i) { idx[i] = rd.decimal(); if (!rd.ok || idx[i] >= domain) return fail("pk blob: bad B_query index"); }
-    size_t nval = rd.decimal(); const uint8_t *recB = rd.take(nval * 100);
+    size_t nval = rd.count(100); const uint8_t *recB = rd.take_records(nval, 100);
     if (!rd.ok || nval != nidx) return fail("pk blob: bad B_query values");
     if (decompress<G2Affine>(k_decompress_g2, recB, 100, 0, nval, Bv_g2, 16, d_rec, d_out, d_flag) ||
         decompress<G1Affine>(k_decompress_g1, recB, 100, 66, nval, Bv_g1, 8, d_rec, d_out, d_flag)) return fail(nullptr);
     std::vector<uint64_t> B_g1(domain * 8, 0), B_g2(domain * 16, 0);                    // dense, absent = infinity
     for (size_t i = 0; i < nidx; ++i) { memcpy(&B_g1[idx[i] * 8], &Bv_g1[i * 8], 64); memcpy(&B_g2[idx[i] * 16], &Bv_g2[i * 16], 128); }
     // H_query, L_query
-    size_t nH = rd.decimal(); const uint8_t *recH = rd.take(nH * 34);
-    size_t nL = rd.ok ? rd.decimal() : 0; const uint8_t *recL = rd.take(nL * 34);
+    size_t nH = rd.count(34); const uint8_t *recH = rd.take_records(nH, 34);
+    size_t nL = rd.ok ? rd.count(34) : 0; const uint8_t *recL = rd.take_records(nL, 34);
     if (!rd.ok) return fail("pk blob: bad H/L query");
     if (decompress<G1Affine>(k_decompress_g1, recH, 34, 0, nH, H_query, 8, d_rec, d_out, d_flag) ||
         decompress<G1Affine>(k_decompress_g1, recL, 34, 0, nL, L_query, 8, d_rec, d_out, d_flag)) return fail(nullptr);
     // constraint system
-    size_t primary = rd.decimal(), auxiliary = rd.decimal(), ncons = rd.decimal();
+    size_t primary = rd.count(0), auxiliary = rd.count(0), ncons = rd.count(6);       // a constraint is at least three "0\n" term counts
     if (!rd.ok || primary + auxiliary + 1 != nA || nL != auxiliary) return fail("pk blob: constraint system sizes disagree with the queries");
     std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
     for (int m = 0; m < 3; ++m) { rp[m].reserve(ncons + 1); rp[m].push_back(0); }
     for (size_t c = 0; c < ncons; ++c)
         for (int m = 0; m < 3; ++m) {
-            size_t nt = rd.decimal();
+            size_t nt = rd.count(34);                                       // a term: index digits, newline, 32-byte coefficient
             for (size_t t = 0; t < nt && rd.ok; ++t) {
                 size_t index = rd.decimal(); const uint8_t *coeff = rd.take(32);
                 if (!rd.ok || index >= nA) return fail("pk blob: bad linear term");
@@ -189,4 +199,11 @@ extern "C" zkg_crs *zkg_crs_upload_blob(const void *blob, size_t len) {
     pk.beta_g2 = small2.data(); pk.delta_g2 = small2.data() + 16;
     pk.A_query = A_query.data(); pk.B_g1 = B_g1.data(); pk.B_g2 = B_g2.data(); pk.H_query = H_query.data(); pk.L_query = L_query.data();
     return zkg_crs_upload(&pk);
+}
+
+// Nothing may propagate through the C boundary: allocation failures on hostile sizes end up here as an error return.
+extern "C" zkg_crs *zkg_crs_upload_blob(const void *blob, size_t len) {
+    try { return crs_upload_blob_impl(blob, len); }
+    catch (const std::exception &e) { set_error(std::string("zkg_crs_upload_blob: ") + e.what()); return nullptr; }
+    catch (...) { set_error("zkg_crs_upload_blob: unexpected exception"); return nullptr; }
 }

@@ -8,7 +8,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
-#include "curve.cuh"
+#include "curve.hip.hpp"
 
 namespace zk {
 

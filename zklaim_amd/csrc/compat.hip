@@ -14,6 +14,8 @@
 #include "../../include/zklaim_abi.h"
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <future>
 #include <map>
 #include <mutex>
 #include <random>
@@ -34,8 +36,9 @@ namespace {
 
 std::mutex g_mu;
 bool g_inited = false;
-struct CachedCrs { uint64_t digest; size_t size; zkg_crs *crs; };
-std::map<uint64_t, CachedCrs> g_crs_cache;                    // keyed by a digest of ctx->pk: one upload per key, not per proof
+struct Digest128 { uint64_t a = 0, b = 0; bool operator==(const Digest128 &o) const { return a == o.a && b == o.b; } };
+struct CachedCrs { size_t size; Digest128 full; zkg_crs *crs; };
+std::map<uint64_t, CachedCrs> g_crs_cache;                    // one upload per key, not per proof (the reference re-parses ctx->pk on every call)
 
 int ensure_init() {
     if (g_inited) return 0;
@@ -44,15 +47,18 @@ int ensure_init() {
     g_inited = true;
     return 0;
 }
-// Cache key of a pk blob: FNV-style mixing, 8 bytes at a time, over the head, the tail and 128 strided 512-byte windows (80 KB of a
-// 10-200 MB blob: two different keys differ in every group element, so any window tells them apart; the size is mixed in too).
-uint64_t digest(const unsigned char *p, size_t n) {
+// Two digests of a pk blob.  `sampled` is the cache's lookup key: head, tail and 128 strided windows (80 KB), microseconds on a
+// 10-200 MB blob.  It cannot see an edit between its windows, so a hit is only trusted once `full` — every byte, 128 bits, chunks
+// hashed on the host pool — equals the digest recorded when the resident key was uploaded; libsnark_prove computes it on a helper
+// thread while the GPU already proves with the candidate key and discards that proof on a mismatch.
+inline uint64_t mix64(uint64_t h, uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+uint64_t sampled_digest(const unsigned char *p, size_t n) {
     uint64_t h = 1469598103934665603ull;
     auto eat = [&](size_t lo, size_t hi) {
         if (hi > n) hi = n;
         size_t i = lo;
-        for (; i + 8 <= hi; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
-        for (; i < hi; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        for (; i + 8 <= hi; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = mix64(h, w); }
+        for (; i < hi; ++i) h = mix64(h, p[i]);
     };
     if (n <= (1u << 16)) eat(0, n);
     else {
@@ -61,6 +67,22 @@ uint64_t digest(const unsigned char *p, size_t n) {
         for (size_t k = 1; k < 128; ++k) eat(k * step, k * step + 512);
     }
     return h ^ (n * 0x9E3779B97F4A7C15ull);
+}
+Digest128 full_digest(const unsigned char *p, size_t n) {
+    const size_t CHUNK = (size_t)1 << 18;
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    std::vector<Digest128> part(nchunks);
+    host_parallel_for((int)nchunks, [&](int c) {
+        const size_t lo = (size_t)c * CHUNK, hi = std::min(n, lo + CHUNK);
+        uint64_t l[4] = {0x243F6A8885A308D3ull ^ (uint64_t)c, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};    // four independent lanes
+        size_t i = lo;
+        for (; i + 32 <= hi; i += 32) { uint64_t w[4]; memcpy(w, p + i, 32); for (int k = 0; k < 4; ++k) l[k] = mix64(l[k], w[k]); }
+        for (; i < hi; ++i) l[0] = mix64(l[0], p[i]);
+        part[c] = {mix64(mix64(l[0], l[1]), l[2] + 0x9E37ull), mix64(mix64(l[3], l[2]), l[0] + 0x79B9ull)};
+    });
+    Digest128 d{n * 0x9E3779B97F4A7C15ull, ~(uint64_t)n};
+    for (const Digest128 &x : part) { d.a = mix64(d.a, x.a); d.b = mix64(d.b ^ x.a, x.b); }
+    return d;
 }
 void random_fr_mont(uint64_t out[4]) {
     std::random_device rd;
@@ -108,16 +130,21 @@ int libsnark_prove(zklaim_ctx *ctx) {
     if (!ctx || !ctx->pk || !ctx->pk_size) return ZKLAIM_ERROR;
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return ZKLAIM_ERROR;
-    uint64_t d = digest(ctx->pk, ctx->pk_size);
-    zkg_crs *crs = nullptr;
-    auto it = g_crs_cache.find(d);
-    if (it != g_crs_cache.end() && it->second.size == ctx->pk_size) crs = it->second.crs;
-    else {
-        crs = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
-        if (!crs) return ZKLAIM_ERROR;
+    const uint64_t key = sampled_digest(ctx->pk, ctx->pk_size);
+    auto upload = [&](const Digest128 &full) -> zkg_crs * {
+        zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
+        if (!c) return nullptr;
+        auto old = g_crs_cache.find(key);
+        if (old != g_crs_cache.end()) { zkg_crs_free(old->second.crs); g_crs_cache.erase(old); }
         if (g_crs_cache.size() >= 4) { for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs); g_crs_cache.clear(); }
-        g_crs_cache[d] = {d, ctx->pk_size, crs};
-    }
+        g_crs_cache[key] = {ctx->pk_size, full, c};
+        return c;
+    };
+    zkg_crs *crs = nullptr;
+    bool speculative = false;                                    // a cache hit by the sampled digest: confirmed by the full one below
+    auto it = g_crs_cache.find(key);
+    if (it != g_crs_cache.end() && it->second.size == ctx->pk_size) { crs = it->second.crs; speculative = true; }
+    else if (!(crs = upload(full_digest(ctx->pk, ctx->pk_size)))) return ZKLAIM_ERROR;
     // the witness only: the constraint system already sits on the GPU inside the resident key, and pb.is_satisfied()
     // (snark.cpp:121-124) is evaluated there, fused with the R1CS mat-vec of the prover (check_satisfied = 1)
     zkg_circuit *ck = zkg_zklaim_witness_new(ctx);
@@ -129,10 +156,23 @@ int libsnark_prove(zklaim_ctx *ctx) {
     size_t len = 0;
     const uint8_t *tags = nullptr; const uint32_t *fidx = nullptr; const uint64_t *fval = nullptr; size_t nfull = 0;
     int prc = ZKG_ERROR;                                         // the witness goes up as tags + the few non-bit values (30x less PCIe traffic)
-    if (proof && zkg_circuit_sparse_witness(ck, &tags, &fidx, &fval, &nfull) == ZKG_OK)
-        prc = zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s, 1, proof, &len);
+    if (proof && zkg_circuit_sparse_witness(ck, &tags, &fidx, &fval, &nfull) == ZKG_OK) {
+        std::future<Digest128> confirm;
+        if (speculative) confirm = std::async(std::launch::async, [&] { return full_digest(ctx->pk, ctx->pk_size); });     // under the GPU's work
+        // a key made for another payload count has another variable count: refuse instead of reading past the witness
+        if (zkg_circuit_num_variables(ck) != zkg_crs_num_variables(crs)) set_error("libsnark_prove: ctx->pk was generated for a different circuit (variable count differs)");
+        else prc = zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s, 1, proof, &len);
+        if (speculative) {
+            const Digest128 full = confirm.get();
+            if (!(full == g_crs_cache[key].full)) {              // same size and samples, different bytes: not the resident key after all
+                prc = ZKG_ERROR;
+                crs = upload(full);
+                if (crs && zkg_circuit_num_variables(ck) == zkg_crs_num_variables(crs)) prc = zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s, 1, proof, &len);
+            }
+        }
+    }
     if (prc == ZKG_OK) { ctx->proof = proof; ctx->proof_size = len; rc = ZKLAIM_OK; }          // libsnark_wrapper.cpp:242
-    else { free(proof); if (prc == ZKG_UNSATISFIED && strstr(zkg_last_error(), "not satisfied")) rc = 1; }   // "system not satisfied!! not creating proof."
+    else { free(proof); if (prc == ZKG_UNSATISFIED) rc = 1; }                                  // "system not satisfied!! not creating proof." -> 1
     zkg_circuit_free(ck);
     return rc;
 }

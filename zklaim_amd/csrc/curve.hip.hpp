@@ -1,4 +1,4 @@
-// curve.cuh — alt_bn128 G1 (over Fq) and G2 (over Fq2) group law, y^2 = x^3 + b, a = 0.
+// curve.hip.hpp — alt_bn128 G1 (over Fq) and G2 (over Fq2) group law, y^2 = x^3 + b, a = 0.
 //
 // Replaces libff's alt_bn128_G1 / alt_bn128_G2 add, mixed_add, dbl, to_affine_coordinates
 // (reached from the multi_exp calls inside r1cs_gg_ppzksnark_prover, /root/reference/zklaim/snark.cpp:126).
@@ -9,7 +9,7 @@
 // elements are exact, so any coordinate system gives the same affine result; outputs cross the
 // ABI only in normalised form (include/zkg.h).  Infinity: ZZ == 0 (XYZZ), x == y == 0 (affine).
 #pragma once
-#include "fp.cuh"
+#include "fp.hip.hpp"
 
 // Device code inlines every group operation: a G2 point is 64 registers, more than the calling convention passes in
 // VGPRs, so an out-of-line add or dbl forces its operands (and, through `this`, whole accumulators) into scratch

@@ -1,4 +1,4 @@
-// fp.cuh — alt_bn128 prime-field arithmetic for gfx950 (and the host side of the same library).
+// fp.hip.hpp — alt_bn128 prime-field arithmetic for gfx950 (and the host side of the same library).
 //
 // Replaces libff's Fp_model<4, modulus> / Fp2_model (alt_bn128_Fq, alt_bn128_Fr, alt_bn128_Fq2),
 // reached from r1cs_gg_ppzksnark_prover at /root/reference/zklaim/snark.cpp:126.
@@ -49,7 +49,7 @@ struct alignas(16) Fp {
     static ZK_HD Fp zero() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
     static ZK_HD Fp one() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::ONE[i]; return r; }
     static ZK_HD Fp r2() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::R2[i]; return r; }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+#if defined(__HIP_DEVICE_COMPILE__)
     ZK_HD bool is_zero() const {                     // lazy representation: 0 or p
         uint32_t o = 0, q = 0;
         for (int i = 0; i < 8; ++i) { o |= v[i]; q |= v[i] ^ PR::P[i]; }
@@ -75,7 +75,7 @@ struct alignas(16) Fp {
         return r;
     }
     friend ZK_HD Fp operator+(const Fp &a, const Fp &b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+#if defined(__HIP_DEVICE_COMPILE__)
         // lazy: a, b < 2p, a + b < 4p < 2^256; folded once with 2p.  Two interleaved carry chains (tools/gen_mont_asm.py): 34 full-rate
         // issue slots against the compiler's ~90 instructions with 32 half-rate 64-bit adds.
         Fp r; uint64_t c;
@@ -97,21 +97,11 @@ struct alignas(16) Fp {
         uint32_t t[8]; uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[j] + b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
-#if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t s[8]; uint32_t br = 0;                 // lazy (ZK_MONT_CXX build): fold once with 2p
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)t[j] - PR::TWO_P[j] - br; s[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
-        Fp r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[j] = br ? t[j] : s[j];
-        return r;
-#else
         return reduce_once(t);               // p < 2^254: a + b < 2^255 never carries out
-#endif
 #endif
     }
     friend ZK_HD Fp operator-(const Fp &a, const Fp &b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+#if defined(__HIP_DEVICE_COMPILE__)
         Fp r; uint64_t c;                                // lazy: a - b, plus 2p when it borrowed; same interleaved scheme as operator+
         if constexpr (std::is_same<PR, FqParams>::value) {
             asm(ZK_FP_SUB_ASM_FQ
@@ -134,11 +124,7 @@ struct alignas(16) Fp {
         uint32_t mask = 0u - br; uint64_t c = 0; Fp r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            c += (uint64_t)t[j] + (PR::TWO_P[j] & mask);
-#else
             c += (uint64_t)t[j] + (PR::P[j] & mask);
-#endif
             r.v[j] = (uint32_t)c; c >>= 32;
         }
         return r;
@@ -149,7 +135,7 @@ struct alignas(16) Fp {
 
     // Montgomery product a*b*R^-1 mod p.
     friend ZK_HD Fp operator*(const Fp &a, const Fp &b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MONT_CXX)
+#if defined(__HIP_DEVICE_COMPILE__)
         // Hand-scheduled gfx950 stream (tools/gen_mont_asm.py): product scanning with a 96-bit column accumulator,
         // one v_mad_u64_u32 + one v_addc_co_u32 per partial product.  Result in [0, 2p).
         uint32_t t[8]; uint64_t c0, c1, c2;
@@ -170,8 +156,6 @@ struct alignas(16) Fp {
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.v[j] = t[j];
         return r;
-#elif defined(__HIP_DEVICE_COMPILE__)
-        // portable C++ form of the same product (kept for A/B checks: -DZK_MONT_CXX): CIOS over 32-bit limbs
 #else
         typedef unsigned __int128 u128;
         uint64_t A[4], B[4], P4[4], t[4] = {0, 0, 0, 0};

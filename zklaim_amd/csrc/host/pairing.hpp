@@ -11,7 +11,7 @@
 // representation bit for bit (libff may differ by a fixed unit power), which only matters for exchanging vk blobs.
 #pragma once
 #include <vector>
-#include "../curve.cuh"
+#include "../curve.hip.hpp"
 
 namespace zk { namespace pairing {
 

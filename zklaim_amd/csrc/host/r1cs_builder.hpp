@@ -7,7 +7,7 @@
 #include <cstring>
 #include <utility>
 #include <vector>
-#include "../fp.cuh"
+#include "../fp.hip.hpp"
 
 namespace zk { namespace circuit {
 
@@ -42,9 +42,9 @@ struct Builder {
     bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
     // A view allocates from a pre-sized range [cursor, cursor_end) of its root's storage and reads / writes values there: the
     // per-payload sub-circuits of a witness-only pass are independent and run on separate threads through views.
-    Builder *root = nullptr; uint32_t cursor = 0, cursor_end = 0;
+    Builder *root = nullptr; uint32_t cursor = 0, cursor_end = 0, cursor_begin = 0; bool overrun = false;
     Builder() { val.push_back(Fr::one()); nz.push_back(1); }
-    static Builder view_of(Builder &r, uint32_t begin, uint32_t end) { Builder v; v.root = &r; v.cursor = begin; v.cursor_end = end; v.recording = r.recording; return v; }
+    static Builder view_of(Builder &r, uint32_t begin, uint32_t end) { Builder v; v.root = &r; v.cursor = v.cursor_begin = begin; v.cursor_end = end; v.recording = r.recording; return v; }
     // append the constraints a view recorded (views keep their own cons / arena; merged in payload order the result is the serial one)
     void absorb(const Builder &v) {
         const uint32_t base = (uint32_t)arena.size();
@@ -55,7 +55,11 @@ struct Builder {
     void reserve(size_t nvars) { val.reserve(nvars + 1); nz.reserve(nvars + 1); }
     uint32_t extend(size_t count) { uint32_t first = (uint32_t)val.size(); val.resize(val.size() + count, Fr::zero()); nz.resize(nz.size() + count, 0); return first; }
     Var alloc() {
-        if (root) return cursor < cursor_end ? cursor++ : (cursor++, 0);     // overrun is detected by the caller (cursor > cursor_end)
+        if (root) {                                                          // a view: its own pre-sized range only
+            if (cursor < cursor_end) return cursor++;
+            overrun = true;                                                  // reported by the caller; the stand-in is one of the view's OWN variables
+            return cursor_end > cursor_begin ? cursor_end - 1 : (Var)(root->val.size() - 1);     // (never the constant ONE, never another view's)
+        }
         val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1);
     }
     void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = x.is_zero() ? 0 : (x == Fr::one() ? 1 : 2); }

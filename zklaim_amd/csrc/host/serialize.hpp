@@ -4,7 +4,7 @@
 #pragma once
 #include <cstring>
 #include <vector>
-#include "../curve.cuh"
+#include "../curve.hip.hpp"
 #include "pairing.hpp"
 
 namespace zk { namespace ser {

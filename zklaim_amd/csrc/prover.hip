@@ -340,6 +340,8 @@ void zkg_crs_free(zkg_crs *crs) {
     delete crs;
 }
 
+uint32_t zkg_crs_num_variables(const zkg_crs *crs) { return crs ? crs->n : 0; }
+
 int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }

@@ -7,8 +7,8 @@
 // Generator: swap A and B when B touches more variables (libsnark's swap_AB_if_beneficial: fewer G2 bases), evaluate the QAP
 // at the trapdoor point t on the host (Lagrange coefficients in closed form with one batched inversion, then one pass over
 // the non-zeros), and turn the ~4n + m scalars into curve points with the fixed-base kernels of msm.hip on the GPU — the part
-// that dominates the reference's setup time.  Domain: m = next power of two >= C + l + 1 (libfqfft would pick a
-// step_radix2 domain for some sizes; this build always uses basic radix-2 domains).
+// that dominates the reference's setup time.  Domain: libfqfft's get_evaluation_domain(C + l + 1) rule
+// (evaluation_domain_shape, ntt.hip): basic_radix2_domain or step_radix2_domain, Lagrange coefficients from domain_lagrange.
 // Verifier: host pairing (host/pairing.hpp); the public input is folded into gamma_ABC with host scalar multiplications.
 #include "common.hpp"
 #include <algorithm>
@@ -226,7 +226,7 @@ size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
 
 // r1cs_gg_ppzksnark_verifier_strong_IC: 0 = proof valid, 1 = invalid (libsnark_verify returns !valid, libsnark_wrapper.cpp:269),
 // 2 = malformed key / proof.  primary_input: n_inputs x 4 limbs, Montgomery Fr.
-int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
+static int groth16_verify_impl(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
     if (!vk_blob || !proof || (n_inputs && !primary_input)) { set_error("zkg_groth16_verify: null argument"); return 2; }
     ser::Reader rd{vk_blob, vk_blob + vk_len};
     const uint8_t *gt = rd.take(384), *pg = rd.take(66), *pd = rd.take(66), *p0 = rd.take(34);
@@ -235,11 +235,14 @@ int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *pr
     G2Affine gamma_g2, delta_g2; G1Affine ic0;
     if (!ser::get_g2(pg, gamma_g2) || !ser::get_g2(pd, delta_g2) || !ser::get_g1(p0, ic0)) { set_error("vk blob: bad point"); return 2; }
     size_t domain = rd.dec(), nidx = rd.dec();
-    if (!rd.ok || nidx > domain) { set_error("vk blob: bad gamma_ABC header"); return 2; }
+    // counts are bounded by the bytes that can still follow (an index takes >= 2 bytes, a value 34) before anything is sized by them
+    if (!rd.ok || nidx > domain || nidx > (size_t)(rd.end - rd.p) / 2) { set_error("vk blob: bad gamma_ABC header"); return 2; }
     std::vector<size_t> idx(nidx);
     for (auto &i : idx) { i = rd.dec(); if (!rd.ok || i >= domain) { set_error("vk blob: bad index"); return 2; } }
-    size_t nval = rd.dec(); const uint8_t *vals = rd.take(nval * 34);
-    if (!rd.ok || nval != nidx) { set_error("vk blob: bad gamma_ABC values"); return 2; }
+    size_t nval = rd.dec();
+    if (!rd.ok || nval != nidx || nval > (size_t)(rd.end - rd.p) / 34) { set_error("vk blob: bad gamma_ABC values"); return 2; }
+    const uint8_t *vals = rd.take(nval * 34);
+    if (!rd.ok) { set_error("vk blob: truncated gamma_ABC values"); return 2; }
     if (domain != n_inputs) return 1;                                           // strong input consistency: sizes must agree
     if (proof_len != ZKG_PROOF_BYTES) return 1;
     G1Affine pA, pC; G2Affine pB;
@@ -263,6 +266,12 @@ int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *pr
     ml(pA, pB); ml(accA.neg(), gamma_g2); ml(pC.neg(), delta_g2);
     Fq12 f = Ps.empty() ? Fq12::one() : pairing::multi_miller_loop(Ps.data(), Qs.data(), (int)Ps.size());   // three loops in lock-step
     return pairing::final_exponentiation(f) == alpha_beta ? 0 : 1;
+}
+
+int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
+    try { return groth16_verify_impl(vk_blob, vk_len, primary_input, n_inputs, proof, proof_len); }       // nothing propagates through the C boundary
+    catch (const std::exception &e) { set_error(std::string("zkg_groth16_verify: ") + e.what()); return 2; }
+    catch (...) { set_error("zkg_groth16_verify: unexpected exception"); return 2; }
 }
 
 // bilinearity probe for the tests: writes e(a*G1, b*G2) (384 B) for canonical scalars a, b

@@ -5,9 +5,12 @@
 // (zklaim/zklaim_gadget.cpp:153-784) and zklaim_input_map (zklaim_gadget.cpp:115-150).  The statement is the reference's:
 // per payload, SHA-256(pre) == hash for the 48-byte pre-image, each of the five 64-bit attributes stands in the relation
 // selected by the one-hot op to its reference value, exactly one op is selected per attribute, the compared values are
-// tied to plvars — and, like the reference, the pack_PL / pack_REF / pack_OPS packings are witness-only: their
-// constraints are never generated (zklaim_gadget.cpp:583-699 never calls them), so refvals / opsvals / plvars are not
-// bound to the public bits.  That quirk is reproduced, not repaired, unless ZKG_BIND_PACKINGS=1 is set.
+// tied to plvars.  One deliberate difference: the reference assigns the pack_PL / pack_REF / pack_OPS packings as witnesses
+// (zklaim_gadget.cpp:768-769,780) but never generates their constraints (absent from :583-699), which leaves refvals /
+// opsvals / plvars free: a prover who knows the pre-image could then satisfy ANY public predicate (set the op one-hot to noop).
+// Keys made here are not interchangeable with libsnark-made keys anyway (gadgets.hpp), so the packings ARE enforced here
+// (78 more constraints per payload, no extra variable, same witness).  ZKG_CIRCUIT_REFERENCE_QUIRK (include/zkg.h) asks
+// for the reference's unbound shape; the choice lives in the constraint system inside the key, not in the process.
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include "../../include/zklaim_abi.h"
@@ -75,7 +78,7 @@ void give_storage(Builder &pb) {
 }
 }  // namespace
 
-static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool witness_only = false) {
+static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool witness_only = false, bool reference_quirk = false) {
     zkg_circuit *ck = new zkg_circuit();
     Builder &pb = ck->pb;
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
@@ -85,7 +88,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
     pb.recording = !witness_only;                           // proving: the resident key already holds the constraint system
     pb.reserve(28000 * (ctx->num_of_payloads + 1));
     const size_t k = ctx->num_of_payloads;
-    const bool bind_packings = getenv("ZKG_BIND_PACKINGS") != nullptr;
+    const bool bind_packings = !reference_quirk;
     std::vector<const zklaim_payload *> pls;
     for (const zklaim_wrap_payload_ctx *cur = ctx->pl_ctx_head; cur; cur = cur->next) pls.push_back(&cur->pl);
     if (pls.size() != k) { delete ck; set_error("zklaim circuit: num_of_payloads disagrees with the payload list"); return nullptr; }
@@ -210,7 +213,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
             v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
             if (v.recording) { v.cons.reserve(cons_per); v.arena.reserve(terms_per); }
             payload_gadgets(v, (size_t)t + first_parallel);
-            bad[t] = v.cursor != v.cursor_end;
+            bad[t] = v.overrun || v.cursor != v.cursor_end;
         });
         for (char b : bad) if (b) { known_vars = 0; delete ck; set_error("zklaim circuit: payload sub-circuits differ in size"); return nullptr; }
         if (pb.recording) for (const Builder &v : views) pb.absorb(v);
@@ -228,9 +231,9 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
 
 extern "C" {
 
-zkg_circuit *zkg_zklaim_circuit_new(const zklaim_ctx *ctx, int with_witness) {
+zkg_circuit *zkg_zklaim_circuit_new(const zklaim_ctx *ctx, int flags) {
     if (!ctx) { set_error("zkg_zklaim_circuit_new: null ctx"); return nullptr; }
-    return build_zklaim(ctx, with_witness != 0);
+    return build_zklaim(ctx, (flags & ZKG_CIRCUIT_WITH_WITNESS) != 0, false, (flags & ZKG_CIRCUIT_REFERENCE_QUIRK) != 0);
 }
 // witness only (generate_r1cs_witness without re-deriving the constraints): what a prover holding a resident key needs
 zkg_circuit *zkg_zklaim_witness_new(const zklaim_ctx *ctx) {
