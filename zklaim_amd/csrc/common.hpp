@@ -90,6 +90,14 @@ void ntt_release_all();
 int ntt_configure();
 
 // ---------------- MSM (msm.hip) ----------------
+static constexpr int MSM_MAX_SETS = 4;                      // base sets sharing one digit sort (the prover: A, B_g1, L and B_g2 over one witness)
+// one base set of a launch.  level_stride > 0: a per-window table (window_table_build_*): level w of the table, at p + w * level_stride
+// elements, holds 2^(c w) P_i, so every window shares one bucket set and the host has no doublings left.  index_sub: entry i of the
+// scalars stands for element i - index_sub of the set (the L query starts behind the constant and the public inputs); smaller i: no base.
+struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; };
+struct WindowTable { DevBuf buf; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); n = 0; } };
+int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s);
+int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s);
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
 MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);
 hipStream_t msm_job_stream(MsmJob *j);
@@ -97,8 +105,15 @@ void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws);   // the jo
 void msm_job_set_skewed(MsmJob *j, bool skewed);            // scalars known to be mostly equal (0/1 witness): use the one-pass sort directly
 void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_destroy(MsmJob *j);
-int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont);
-int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);
+// d_gather (optional, n entries): scalar i is d_scalars[d_gather[i]] and stands for element d_gather[i] of every base set
+int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t *d_scalars, size_t n, bool scalars_mont, const uint32_t *d_gather = nullptr);
+int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);   // out_g1[k]: k-th G1 set of the launch, out_g2[k]: k-th G2 set
+// the multi_exp_with_mixed_addition split of a witness z = [1 | w] (n1 elements, Montgomery): tags (0 zero, 1 one, 2 other), the
+// indices of the others and their count; and the flat sum of the bases tagged one (result lands in pinned host memory)
+int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s);
+struct OnesSum { DevBuf partials; void *host = nullptr; bool g2 = false; void release(); };
+int ones_sum_launch_g1(OnesSum &o, const G1Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s);
+int ones_sum_launch_g2(OnesSum &o, const G2Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s);
 // scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  Zero scalars are dropped and ones land in
 // one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s, bool mostly_bits = false);

@@ -59,7 +59,21 @@ static constexpr int SCAN_ITEMS = 4;         // per thread in the block scan
 // window bits, windows handled by this launch, buckets per window (2^(c-1)); the launch owns windows w0, w0 + ws, ... of the Wt
 // windows of the scalar (w0 = 0, ws = 1: all of them; a window-sharded multi-GPU run gives rank g the set w0 = g, ws = G)
 struct MsmGeom { uint32_t c, W, B, Wt, w0, ws; };
-struct HeavyItem { uint32_t start, end; };   // a part: range of the sorted index list
+// How a sorted entry finds its base.  Plain set: bases[i].  Per-window table of a resident key (level w holds 2^(c w) P_i, built once by
+// window_table_build): bases[w * level_stride + i], w = the window of the entry's bucket — every window's digit then weighs the same, so
+// the W bucket sets are summed bucket-wise (k_bucket_fold) and reduced ONCE, and no doubling is left for the host.  `gather`: the scalars
+// were a gathered subset (a witness' non-bit values); entry i stands for element gather[i] of the set.  `index_sub`: the set starts at
+// that element (the L query starts behind the public inputs); entries below it belong to no base of this set.
+template <class F> struct BaseView {
+    const Affine<F> *p; size_t level_stride; const uint32_t *gather; uint32_t index_sub, B;
+    ZK_D Affine<F> load(uint32_t e, size_t gb) const {
+        uint32_t i = e >> 1;
+        if (gather) i = gather[i];
+        if (i < index_sub) return Affine<F>::inf();
+        return p[(level_stride ? (gb / B) * level_stride : 0) + (i - index_sub)];
+    }
+};
+struct HeavyItem { uint32_t start, end, gb; };   // a part: range of the sorted index list, and the bucket it belongs to
 struct HeavyBucket { uint32_t gb, first_item, nparts; };
 
 // Window size.  Measured on MI355X with uniformly random scalars (tools/msm_c_sweep.py): the accumulation runs one lane per
@@ -89,11 +103,11 @@ ZK_D uint32_t bits_at(const uint32_t v[8], uint32_t off, uint32_t c) {
 }
 
 // digit code: 0 = no contribution; otherwise ((bucket + 1) << 1) | negative, bucket = |d| - 1
-__global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, size_t n, int mont, MsmGeom g, uint32_t *digits) {
+__global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, const uint32_t *gather, size_t n, int mont, MsmGeom g, uint32_t *digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr f;
-    const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * i);
+    const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * (gather ? (size_t)gather[i] : i));
     uint4 a = p[0], b = p[1];
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
     if (mont) f = f.from_mont();
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, co
 
 // ---- 6. bucket accumulation (dominant kernel) -------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+__global__ __launch_bounds__(256) void k_bucket_accum(const BaseView<F> bases, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
                                                        size_t total_buckets, XYZZ<F> *buckets,
                                                        HeavyItem *items, HeavyBucket *heavy, uint32_t *counters /* [0] items, [1] heavy buckets */) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,18 +434,18 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const Affine<F> *bases, co
     if (end - k > heavy_t) {
         uint32_t nparts = (end - k + HEAVY_S - 1) / HEAVY_S;
         uint32_t first = atomicAdd(&counters[0], nparts);
-        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end}; }
+        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb}; }
         heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
         return;
     }
     XYZZ<F> acc = XYZZ<F>::inf();
     if (k < end) {
         uint32_t e = sorted[k];
-        Affine<F> p = bases[e >> 1];
+        Affine<F> p = bases.load(e, gb);
         while (true) {
             Affine<F> cur = p; uint32_t ce = e;
             ++k;
-            if (k < end) { e = sorted[k]; p = bases[e >> 1]; }            // prefetch the next base under this addition
+            if (k < end) { e = sorted[k]; p = bases.load(e, gb); }        // prefetch the next base under this addition
             if (ce & 1u) cur.y = cur.y.neg();
             acc.madd(cur);
             if (k >= end) break;
@@ -456,7 +470,7 @@ ZK_D void lds_tree_reduce(XYZZ<F> *seg, uint32_t n, uint32_t tid, uint32_t nthre
 
 // one wavefront per heavy part: 64 lanes stride over <= HEAVY_S entries, then a 6-level LDS tree
 template <class F>
-__global__ __launch_bounds__(256) void k_heavy_parts(const Affine<F> *bases, const uint32_t *sorted, const HeavyItem *items,
+__global__ __launch_bounds__(256) void k_heavy_parts(const BaseView<F> bases, const uint32_t *sorted, const HeavyItem *items,
                                                       const uint32_t *counters, XYZZ<F> *partials) {
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const Affine<F> *bases, con
             HeavyItem h = items[it];
             for (uint32_t k = h.start + lane; k < h.end; k += 64) {
                 uint32_t e = sorted[k];
-                Affine<F> p = bases[e >> 1];
+                Affine<F> p = bases.load(e, h.gb);
                 if (e & 1u) p.y = p.y.neg();
                 acc.madd(p);
             }
@@ -550,11 +564,84 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
     }
 }
 
+// ---- 7b. per-window tables: all W windows weigh the same, so their bucket sets are summed bucket-wise before the one reduction.
+//      One DPP quad per bucket walks the W accumulators (most are infinity for a sparse witness: xyzz_add_quad returns at once).
+template <class F>
+__global__ __launch_bounds__(256) void k_bucket_fold(const XYZZ<F> *buckets, uint32_t W, uint32_t B, XYZZ<F> *out) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid >> 2, q = gid & 3;
+    if (b >= B) return;
+    XYZZ<F> acc = buckets[b];
+    for (uint32_t w = 1; w < W; ++w) xyzz_add_quad(acc, buckets[(size_t)w * B + b], q);
+    if (q == 0) out[b] = acc.normalized();
+}
+
+// level j+1 of a window table from level j: out_i = 2^c in_i (c doublings in XYZZ, one inversion back to affine)
+template <class F>
+__global__ __launch_bounds__(256) void k_table_level(const Affine<F> *in, Affine<F> *out, size_t n, uint32_t c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = in[i];
+    if (a.is_inf()) { out[i] = a; return; }
+    XYZZ<F> p = XYZZ<F>::dbl_affine_inl(a);
+    for (uint32_t k = 1; k < c; ++k) p = p.dbl();
+    XYZZ<F> fin = p;                       // to_affine() is out of line: only this copy has its address taken
+    out[i] = fin.to_affine().normalized();
+}
+
+// ---- witness split (libff multi_exp_with_mixed_addition, reached from snark.cpp:126 for the A / B / L queries): a scalar that is 0 is
+//      skipped, a scalar that is 1 adds its base directly, anything else is left to the bucket method.  k_classify tags every element
+//      of z = [1 | w] (0 zero, 1 one, 2 other) and lists the indices of the others; k_ones_sum adds the bases tagged 1 (a flat sum: lanes
+//      stride over the tags, LDS tree per workgroup, k_sum_partials finishes); the listed ones go through the digit sort as a gathered
+//      subset.  Both parts are exact group sums, so their total is the same point the reference's loop produces.
+__global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_t *tags, uint32_t *listed, uint32_t *count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tag = 0;
+    if (i < n1) {
+        Fr v = z[i];
+        uint32_t any = 0, diff = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { any |= v.v[j]; diff |= v.v[j] ^ FrParams::ONE[j]; }
+        tag = any == 0 ? 0u : (diff == 0 ? 1u : 2u);
+        tags[i] = (uint8_t)tag;
+    }
+    const unsigned long long mask = __ballot(tag == 2);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+    if (tag == 2) listed[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint32_t)i;
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_ones_sum(const Affine<F> *bases, const uint8_t *tags, size_t n1, uint32_t index_sub, XYZZ<F> *partials) {
+    extern __shared__ unsigned char red_smem[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride)
+        if (i >= index_sub && tags[i] == 1) acc.madd(bases[i - index_sub]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    lds_tree_reduce<F>(sh, 256, threadIdx.x, 256, [] { __syncthreads(); });
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0].normalized();
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F> *partials, uint32_t count, XYZZ<F> *out) {
+    extern __shared__ unsigned char red_smem[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t i = threadIdx.x; i < count; i += 256) acc.add(partials[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    lds_tree_reduce<F>(sh, 256, threadIdx.x, 256, [] { __syncthreads(); });
+    if (threadIdx.x == 0) out[0] = sh[0].normalized();
+}
+
 // ---- jobs: one MSM (or several base sets over one scalar vector) in flight on one stream ---------------------
 struct MsmSlot {                    // per base set: accumulators and the host landing zone of its chunk results
-    DevBuf buckets, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
-    void *host_red = nullptr; size_t host_cap = 0; bool g2 = false;
-    uint32_t cpw = 0; size_t nred = 0; int chunk_log = 0;      // reduce geometry: chunks per window, chunk results, log2(buckets per chunk)
+    DevBuf buckets, folded, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
+    void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false;
+    uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
     int host_reserve(size_t bytes) {
         if (bytes <= host_cap) return 0;
         if (host_red) (void)hipHostFree(host_red);
@@ -564,7 +651,7 @@ struct MsmSlot {                    // per base set: accumulators and the host l
         return 0;
     }
     void release() {
-        for (DevBuf *b : {&buckets, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials}) b->release();
+        for (DevBuf *b : {&buckets, &folded, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials}) b->release();
         if (host_red) (void)hipHostFree(host_red);
         host_red = nullptr; host_cap = 0;
     }
@@ -572,17 +659,17 @@ struct MsmSlot {                    // per base set: accumulators and the host l
 struct MsmJob {
     hipStream_t stream = nullptr; bool own_stream = false;
     DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted, rx_tmp, rx_meta;
-    MsmSlot slot[3]; int nslots = 0;
+    MsmSlot slot[MSM_MAX_SETS]; int nslots = 0;
     MsmGeom g{}; size_t n = 0; int red_l_log = RED_L_LOG_SMALL;
     int window_hint = 0;               // 0: pick_geom's rule
     bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
-    int empty_g1 = 0; bool empty_g2 = false;
+    bool empty = false;
     std::mutex mu;
 };
 
 template <class F>
-static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases, bool time_it) {
+static int launch_accumulate(MsmJob *job, MsmSlot &sl, const MsmBases &set, const uint32_t *d_gather, bool time_it) {
     const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B;
     hipStream_t s = job->stream;
     size_t n_entries_max = n * g.W;
@@ -591,39 +678,48 @@ static int launch_accumulate(MsmJob *job, MsmSlot &sl, const Affine<F> *d_bases,
         sl.heavy_counters.reserve(8) || sl.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
     ZK_HIP(hipMemsetAsync(sl.heavy_counters.p, 0, 8, s));
     typedef RedGeom<F> RG;
-    sl.chunk_log = RG::LANES_LOG + job->red_l_log;
-    sl.cpw = (g.B + (1u << sl.chunk_log) - 1) >> sl.chunk_log; sl.nred = (size_t)g.W * sl.cpw;
+    sl.table = set.level_stride != 0;
+    sl.red_windows = sl.table ? 1 : g.W;                             // a table's windows are folded into one bucket set first
+    int red_l_log = (size_t)sl.red_windows * g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
+    sl.chunk_log = RG::LANES_LOG + red_l_log;
+    sl.cpw = (g.B + (1u << sl.chunk_log) - 1) >> sl.chunk_log; sl.nred = (size_t)sl.red_windows * sl.cpw;
     if (sl.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || sl.red_out.reserve(sl.nred * 2 * sizeof(XYZZ<F>)) ||
-        sl.host_reserve(sl.nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
+        (sl.table && sl.folded.reserve((size_t)g.B * sizeof(XYZZ<F>))) || sl.host_reserve(sl.nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
     XYZZ<F> *buckets = sl.buckets.as<XYZZ<F>>();
+    const BaseView<F> view{reinterpret_cast<const Affine<F> *>(set.p), set.level_stride, d_gather, set.index_sub, g.B};
     if (time_it) g_dominant_timer.begin(s);
     hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
-                       d_bases, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, buckets,
+                       view, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, buckets,
                        sl.heavy_items.as<HeavyItem>(), sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>());
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       d_bases, job->sorted.as<uint32_t>(), sl.heavy_items.as<HeavyItem>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>());
+                       view, job->sorted.as<uint32_t>(), sl.heavy_items.as<HeavyItem>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>());
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
                        sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>(), buckets);
-    if (job->red_l_log == RED_L_LOG_LARGE)
+    const XYZZ<F> *red_in = buckets;
+    if (sl.table) {
+        hipLaunchKernelGGL(k_bucket_fold<F>, dim3((unsigned)((4 * (size_t)g.B + 255) / 256)), dim3(256), 0, s, buckets, g.W, g.B, sl.folded.as<XYZZ<F>>());
+        red_in = sl.folded.as<XYZZ<F>>();
+    }
+    if (red_l_log == RED_L_LOG_LARGE)
         hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
-                           buckets, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
+                           red_in, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
     else
         hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
-                           buckets, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
+                           red_in, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
     ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, sl.nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
     return ZKG_OK;
 }
 
 // host: window value V_w = sum_b (b+1) X_b = U_w + P_w, with chunk ch contributing U_ch + (ch*RED_CHUNK) * P_ch to U_w
-// and P_ch to P_w; then Horner over windows (c doublings each).
+// and P_ch to P_w; then Horner over windows (c doublings each).  A table slot arrives as ONE window of weight 1: no doublings at all.
 template <class F>
 static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
-    const MsmGeom g = job->g; const uint32_t cpw = sl.cpw;
+    const MsmGeom g = job->g; const uint32_t cpw = sl.cpw, W = sl.red_windows;
     const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(sl.host_red);
-    std::vector<XYZZ<F>> V(g.W);
-    host_parallel_for((int)g.W, [&](int w) {                                    // the windows are independent
+    std::vector<XYZZ<F>> V(W);
+    auto window = [&](int w) {
         XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
         for (int ch = (int)cpw - 1; ch >= 0; --ch) {
             const XYZZ<F> &P = red[2 * ((size_t)w * cpw + ch)], &U = red[2 * ((size_t)w * cpw + ch) + 1];
@@ -634,10 +730,12 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
         if (!weighted.is_inf()) for (int i = 0; i < sl.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
-    });
+    };
+    if (W == 1) { window(0); return V[0]; }
+    host_parallel_for((int)W, window);                                          // the windows are independent
     // sum_j 2^(c (w0 + j ws)) V_j: Horner with c*ws doublings per owned window, then the shift of the lowest one
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = (int)g.W - 1; w >= 0; --w) {
+    for (int w = (int)W - 1; w >= 0; --w) {
         if (!acc.is_inf()) for (uint32_t i = 0; i < g.c * g.ws; ++i) acc = acc.dbl();
         acc.add(V[w]);
     }
@@ -645,7 +743,7 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
     return acc;
 }
 
-static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
+static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const uint32_t *d_gather) {
     const MsmGeom g = job->g; const size_t n = job->n;
     hipStream_t s = job->stream;
     const size_t total = (size_t)g.W * g.B;
@@ -658,7 +756,7 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont) {
         job->order.reserve(total * 4) || job->sorted.reserve(std::max<size_t>(1, n * g.W) * 4)) return ZKG_ERROR;
     uint32_t *digits = job->digits.as<uint32_t>(), *hist = job->hist.as<uint32_t>(), *counts = job->counts.as<uint32_t>(),
              *offsets = job->offsets.as<uint32_t>(), *sums = job->scan_sums.as<uint32_t>(), *chist = job->class_hist.as<uint32_t>();
-    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, n, (int)mont, g, digits);
+    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_gather, n, (int)mont, g, digits);
     static const bool radix_off = getenv("ZKG_SORT_ONE_PASS") != nullptr;                       // A/B switch
     uint32_t cbits = 6;
     static const uint32_t bin_avg = getenv("ZKG_RX_AVG") ? (uint32_t)atoi(getenv("ZKG_RX_AVG")) : RX_BIN_AVG;     // tuning aid
@@ -718,43 +816,41 @@ void msm_job_destroy(MsmJob *j) {
 
 static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex); only it feeds the kernel timer
 
-// enqueue: one digit sort of `d_scalars`, then one accumulate+reduce per base set (<= 2 G1 sets and <= 1 G2 set)
-int msm_job_launch(MsmJob *job, const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont) {
+// enqueue: one digit sort of the scalars (element d_gather[i] of d_scalars when a gather list is given), then one accumulate + reduce
+// per base set
+int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t *d_scalars, size_t n, bool scalars_mont, const uint32_t *d_gather) {
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *w) { if (dbg) fprintf(stderr, "[zkg]     %-18s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
-    if (n >= ((size_t)1 << 31) || n_g1 > 2) { set_error("msm: bad size"); return ZKG_ERROR; }
+    if (n >= ((size_t)1 << 31) || nsets < 0 || nsets > MSM_MAX_SETS) { set_error("msm: bad size"); return ZKG_ERROR; }
+    bool any_table = false;
+    for (int i = 0; i < nsets; ++i) any_table = any_table || sets[i].level_stride != 0;
+    for (int i = 0; i < nsets; ++i) if ((sets[i].level_stride != 0) != any_table) { set_error("msm: table and plain base sets cannot share a launch"); return ZKG_ERROR; }
+    if (any_table && (job->w0 != 0 || job->ws != 1 || job->window_hint <= 0)) { set_error("msm: a table launch covers all windows at the table's window size"); return ZKG_ERROR; }
     job->g = pick_geom(n, job->window_hint, job->w0, job->ws); job->n = n;
-    job->nslots = 0; job->empty_g1 = 0; job->empty_g2 = false;
-    if (job->g.W == 0) { job->empty_g1 = n_g1; job->empty_g2 = d_g2_bases != nullptr; return ZKG_OK; }     // this rank owns no window: its partial is the identity
+    job->nslots = nsets; job->empty = false;
+    for (int i = 0; i < nsets; ++i) job->slot[i].g2 = sets[i].g2;
+    if (job->g.W == 0 || n == 0) { job->empty = true; return ZKG_OK; }        // no point, or this rank owns no window: the identity
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
-    job->red_l_log = (size_t)job->g.W * job->g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
-    if (sort_digits(job, d_scalars, scalars_mont)) return ZKG_ERROR;
+    if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return ZKG_ERROR;
     lap("sort enqueued");
-    job->nslots = 0;
-    for (int i = 0; i < n_g1; ++i) {
-        MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = false;
-        if (launch_accumulate<Fq>(job, sl, d_g1_bases[i], job == &g_default_job)) return ZKG_ERROR;
-    }
-    if (d_g2_bases) {
-        MsmSlot &sl = job->slot[job->nslots++]; sl.g2 = true;
-        if (launch_accumulate<Fq2>(job, sl, d_g2_bases, n_g1 == 0 && job == &g_default_job)) return ZKG_ERROR;
+    bool timed = false;
+    for (int i = 0; i < nsets; ++i) {
+        MsmSlot &sl = job->slot[i];
+        const bool time_it = job == &g_default_job && !timed && (!sets[i].g2 || nsets == 1);
+        timed = timed || time_it;
+        if (sets[i].g2 ? launch_accumulate<Fq2>(job, sl, sets[i], d_gather, time_it) : launch_accumulate<Fq>(job, sl, sets[i], d_gather, time_it)) return ZKG_ERROR;
     }
     lap("accum enqueued");
     return ZKG_OK;
 }
-// wait for the job's stream and finish on the host; outputs in launch order (G1 sets, then the G2 set)
+// wait for the job's stream and finish on the host; outputs in launch order: out_g1[k] for the k-th G1 set, out_g2[k] for the k-th G2 set
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
     ZK_HIP(hipStreamSynchronize(job->stream));
-    if (job->empty_g1 || job->empty_g2) {
-        for (int i = 0; i < job->empty_g1; ++i) out_g1[i] = G1::inf();
-        if (job->empty_g2) *out_g2 = G2::inf();
-        return ZKG_OK;
-    }
-    int k = 0;
+    int k1 = 0, k2 = 0;
     for (int i = 0; i < job->nslots; ++i) {
-        if (job->slot[i].g2) *out_g2 = host_combine<Fq2>(job, job->slot[i]);
-        else out_g1[k++] = host_combine<Fq>(job, job->slot[i]);
+        if (job->slot[i].g2) out_g2[k2++] = job->empty ? G2::inf() : host_combine<Fq2>(job, job->slot[i]);
+        else out_g1[k1++] = job->empty ? G1::inf() : host_combine<Fq>(job, job->slot[i]);
     }
     return ZKG_OK;
 }
@@ -762,9 +858,13 @@ int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
 
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0, uint32_t ws, bool mostly_bits) {
+    if (n_g1 < 0 || n_g1 + (d_g2_bases ? 1 : 0) > MSM_MAX_SETS) { set_error("msm: too many base sets"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(g_default_job.mu);
     g_default_job.stream = s; g_default_job.w0 = w0; g_default_job.ws = ws ? ws : 1; g_default_job.one_pass_sort = mostly_bits;
-    if (msm_job_launch(&g_default_job, d_g1_bases, n_g1, d_g2_bases, d_scalars, n, scalars_mont)) return ZKG_ERROR;
+    MsmBases sets[MSM_MAX_SETS]; int nsets = 0;
+    for (int i = 0; i < n_g1; ++i) { sets[nsets] = MsmBases(); sets[nsets].p = d_g1_bases[i]; ++nsets; }
+    if (d_g2_bases) { sets[nsets] = MsmBases(); sets[nsets].p = d_g2_bases; sets[nsets].g2 = true; ++nsets; }
+    if (msm_job_launch(&g_default_job, sets, nsets, d_scalars, n, scalars_mont, nullptr)) return ZKG_ERROR;
     return msm_job_finish(&g_default_job, out_g1, out_g2);
 }
 
@@ -774,6 +874,46 @@ int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mo
 int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G2 *out, hipStream_t s, bool mostly_bits) {
     return msm_shared(nullptr, 0, d_bases, d_scalars, n, mont, nullptr, out, s, 0, 1, mostly_bits);
 }
+
+// ---- per-window tables of a resident base set (built once per key) ------------------------------------------------
+template <class F>
+static int window_table_build_t(WindowTable &t, const Affine<F> *d_bases, size_t n, int c, hipStream_t s) {
+    t.n = n; t.c = c; t.W = (SCALAR_BITS + c - 1) / c; t.g2 = sizeof(F) != sizeof(Fq);
+    if (t.buf.reserve(std::max<size_t>(1, n) * t.W * sizeof(Affine<F>))) return ZKG_ERROR;
+    if (!n) return ZKG_OK;
+    Affine<F> *lv = t.buf.as<Affine<F>>();
+    ZK_HIP(hipMemcpyAsync(lv, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, s));
+    for (int w = 1; w < t.W; ++w)
+        hipLaunchKernelGGL(k_table_level<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv + (size_t)(w - 1) * n, lv + (size_t)w * n, n, (uint32_t)c);
+    if (hipGetLastError() != hipSuccess) { set_error("window table launch failed"); return ZKG_ERROR; }
+    return ZKG_OK;
+}
+int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s) { return window_table_build_t<Fq>(t, d_bases, n, c, s); }
+int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s) { return window_table_build_t<Fq2>(t, d_bases, n, c, s); }
+
+// ---- witness split: classification and the flat sum of the bases whose scalar is one ----------------------------------
+int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s) {
+    ZK_HIP(hipMemsetAsync(d_count, 0, 4, s));
+    if (n1) hipLaunchKernelGGL(k_classify, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, d_z, n1, d_tags, d_listed, d_count);
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+template <class F>
+static int ones_sum_launch_t(OnesSum &o, const Affine<F> *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) {
+    // ~4 tagged elements per lane: the sum is a dependency chain per lane, then a 8-level tree per workgroup
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (n1 + 1023) / 1024));
+    o.g2 = sizeof(F) != sizeof(Fq);
+    if (o.partials.reserve((size_t)(blocks + 1) * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    if (!o.host) { if (!hip_ok(hipHostMalloc(&o.host, sizeof(G2), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return ZKG_ERROR; }
+    XYZZ<F> *part = o.partials.as<XYZZ<F>>();
+    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks), dim3(256), 256 * sizeof(XYZZ<F>), s, d_bases, d_tags, n1, index_sub, part);
+    hipLaunchKernelGGL(k_sum_partials<F>, dim3(1), dim3(256), 256 * sizeof(XYZZ<F>), s, part, blocks, part + blocks);
+    if (hipGetLastError() != hipSuccess) { set_error("ones-sum launch failed"); return ZKG_ERROR; }
+    ZK_HIP(hipMemcpyAsync(o.host, part + blocks, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+    return ZKG_OK;
+}
+int ones_sum_launch_g1(OnesSum &o, const G1Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) { return ones_sum_launch_t<Fq>(o, d_bases, d_tags, n1, index_sub, s); }
+int ones_sum_launch_g2(OnesSum &o, const G2Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) { return ones_sum_launch_t<Fq2>(o, d_bases, d_tags, n1, index_sub, s); }
+void OnesSum::release() { partials.release(); if (host) (void)hipHostFree(host); host = nullptr; }
 
 // ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
 template <class F>
@@ -814,6 +954,8 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;

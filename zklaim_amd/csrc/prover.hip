@@ -8,12 +8,13 @@
 //
 // What differs from the reference by design: the pk is parsed and uploaded ONCE (zkg_crs_upload) instead
 // of on every call (libsnark_wrapper.cpp:230 + the by-value copy at snark.cpp:107-109); iFFT's 1/m and
-// the following cosetFFT's g^i are one fused table multiplication; A, B_g1 and B_g2 share one digit sort
-// because they share the scalar vector [1 | w]; the prover randomness (r, s) is an explicit input.
+// the following cosetFFT's g^i are one fused table multiplication; the five queries live on the device as per-window tables
+// (2^(c w) P_i), so a multi-exponentiation is one bucket set, one reduction and no host doublings; the witness queries are split
+// as multi_exp_with_mixed_addition splits them (zeros skipped, ones summed flat, the rest through the bucket method, A / B_g1 / L
+// sharing one digit sort); the prover randomness (r, s) is an explicit input.
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <chrono>
-#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,19 +28,21 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 }  // namespace zk
 
 // Everything one proof in flight needs on top of the shared key: its [1 | w], the three evaluation vectors, the transform
-// scratch, a stream for the mat-vec / NTT pipeline, five MSM jobs (stream + workspace + pinned landing zone each) and the
+// scratch, a stream for the mat-vec / NTT pipeline, three MSM jobs (stream + workspace + pinned landing zone each) and the
 // events that order them.  One per key: keeping two proofs in flight (the host tail of proof i under the GPU work of proof
-// i+1) was built and measured — 3.1 ms per proof against 2.7 ms one at a time at 8 payloads, 2.0 against 1.6 at one — because
-// one proof's five concurrent MSMs already fill the chip, and ten of them contend.
+// i+1) was built and measured in round 1 — slower, because one proof's concurrent MSMs already fill the chip.
 struct ProverSlot {
     zk::DevBuf z, aABC, flag, up_tags, up_idx, up_vals;    // up_*: staging of a sparse witness                   // [1 | w] and aA | aB | aC back to back (batched NTTs)
     zk::DevBuf ntt_scratch;                     // inter-pass scratch, 3 m elements
-    hipStream_t stream = nullptr;               // mat-vec + NTT stream
-    zk::MsmJob *job_a = nullptr, *job_b1 = nullptr, *job_b2 = nullptr, *job_h = nullptr, *job_l = nullptr;
+    zk::DevBuf wtags, wlisted, wcount;          // the witness split: tag per element of z, indices of the non-bit elements, their count
+    hipStream_t stream = nullptr;               // upload + split + mat-vec + NTT stream
+    // witness multi-exponentiations: one job for the three G1 queries (A, B_g1, L share the digit sort), one for B_g2; H on its own
+    zk::MsmJob *job_w1 = nullptr, *job_w2 = nullptr, *job_h = nullptr;
+    zk::OnesSum ones_a, ones_b1, ones_l, ones_b2;
     hipEvent_t ev[20]; bool ev_ok = false, ready = false;
     float stage_ms[8] = {0};
     // the proof in flight between prove_enqueue and prove_finish
-    uint32_t *flag_host = nullptr;              // pinned: lands the satisfiability flag
+    uint32_t *flag_host = nullptr;              // pinned: [0] lands the satisfiability flag, [1] the count of non-bit witness elements
     bool check = false; zk::Fr r, s;
     std::chrono::steady_clock::time_point t0;
 };
@@ -47,7 +50,9 @@ struct ProverSlot {
 struct zkg_crs {
     uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0;
     zk::DevCsr A, B, Cm;
-    zk::DevBuf A_query, B_g1, B_g2, H_query, L_query;
+    // the five queries as per-window tables (level w = 2^(c w) P_i, level 0 = the query itself): windows share one bucket set, one
+    // reduction per multi-exponentiation and no doubling on the host (W x the key in HBM: 6 GB at 37 payloads, 2 % of the 288 GB)
+    zk::WindowTable A_query, B_g1, B_g2, H_query, L_query;
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
     zk::StepDomain *sdom = nullptr;             // ... or step_radix2_domain (m = 2^(log_m-1) + 2^b); exactly one is set
@@ -197,7 +202,10 @@ static int compute_h(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want
         if (cnt) hipLaunchKernelGGL(k_scatter_full, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, S.up_idx.as<uint32_t>(), S.up_vals.as<Fr>(), cnt, n, z);
     }
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, 4, s));
-    if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident from here on
+    // the multi_exp_with_mixed_addition split of z: tags, the indices of the non-bit elements, and their count (read by the host)
+    if (witness_classify(z, (size_t)crs->n + 1, S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), S.wcount.as<uint32_t>(), s)) return ZKG_ERROR;
+    ZK_HIP(hipMemcpyAsync(S.flag_host + 1, S.wcount.p, 4, hipMemcpyDeviceToHost, s));
+    if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident and split from here on
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
@@ -211,6 +219,7 @@ static int compute_h(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want
     if (want_flag) {
         if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, S.flag.as<uint32_t>());
         ZK_HIP(hipMemcpyAsync(flag_out, S.flag.p, 4, hipMemcpyDeviceToHost, s));
+        if (S.ev_ok) (void)hipEventRecord(S.ev[3], s);
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[1], s);
     Fr *scr = S.ntt_scratch.as<Fr>();
@@ -237,30 +246,26 @@ static int compute_h(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want
     return ZKG_OK;
 }
 
+static int table_window_bits(size_t n) {                                    // window size of a query's table, by the size of the query
+    int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    return lg >= 15 ? 16 : lg >= 9 ? 12 : 8;
+}
 static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (S.ready) return ZKG_OK;
     const size_t n = crs->n, m = crs->m;
     bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * 32) == 0 &&
+              S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(4) == 0 &&
               hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
-        // Stream priorities, measured over eight assignments (8 and 38 payloads): the witness multi-exponentiations high, the mat-vec /
-        // NTT stream and H low is the best one (2.41-2.48 ms against 2.49-2.60 with the H path high, 2.8+ with everything equal):
-        // the latency-bound witness kernels get their few wavefronts placed at once, and the wide NTT / H kernels fill what is left.
+        // Stream priorities as measured in round 1: the latency-bound witness multi-exponentiations high (their few wavefronts are placed
+        // at once), the wide mat-vec / NTT stream and H low (they fill what is left).
         ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_lo), "hipStreamCreate", __FILE__, __LINE__);
-        S.job_a = msm_job_create(nullptr, true, true); S.job_b1 = msm_job_create(nullptr, true, true); S.job_b2 = msm_job_create(nullptr, true, true);
-        S.job_h = msm_job_create(nullptr, true, false); S.job_l = msm_job_create(nullptr, true, true);
-        ok = ok && S.job_a && S.job_b1 && S.job_b2 && S.job_h && S.job_l;
-        if (ok) {
-            // Window bits.  H has uniformly random scalars: the size-based rule.  The witness multi-exponentiations (A, B, L) see
-            // mostly 0/1 scalars (one heavy bucket) and few full-size ones, so their time is the bucket reduction's: small windows.
-            const char *cw = getenv("ZKG_MSM_C_W"), *c2 = getenv("ZKG_MSM_C_G2");           // tuning aids
-            int lg = 0; while (((size_t)1 << (lg + 1)) <= n + 1) ++lg;
-            int w1 = cw ? atoi(cw) : (lg <= 15 ? 10 : lg <= 18 ? 11 : 12), w2 = c2 ? atoi(c2) : w1;      // measured at 1 / 8 / 38 payloads
-            for (MsmJob *j : {S.job_a, S.job_b1, S.job_l}) msm_job_set_window(j, w1);
-            msm_job_set_window(S.job_b2, w2);
-            for (MsmJob *j : {S.job_a, S.job_b1, S.job_b2, S.job_l}) msm_job_set_skewed(j, true);      // 0/1 witness: one heavy bucket per job
+        S.job_w1 = msm_job_create(nullptr, true, true); S.job_w2 = msm_job_create(nullptr, true, true); S.job_h = msm_job_create(nullptr, true, false);
+        ok = ok && S.job_w1 && S.job_w2 && S.job_h;
+        if (ok) {                                                            // a table launch runs at the table's window size
+            msm_job_set_window(S.job_w1, crs->A_query.c); msm_job_set_window(S.job_w2, crs->B_g2.c); msm_job_set_window(S.job_h, crs->H_query.c);
         }
     }
     if (ok) {
@@ -272,9 +277,10 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 static void slot_destroy(ProverSlot &S) {
-    for (DevBuf *b : {&S.z, &S.aABC, &S.flag, &S.ntt_scratch, &S.up_tags, &S.up_idx, &S.up_vals}) b->release();
-    msm_job_destroy(S.job_a); msm_job_destroy(S.job_b1); msm_job_destroy(S.job_b2); msm_job_destroy(S.job_h); msm_job_destroy(S.job_l);
-    S.job_a = S.job_b1 = S.job_b2 = S.job_h = S.job_l = nullptr;
+    for (DevBuf *b : {&S.z, &S.aABC, &S.flag, &S.ntt_scratch, &S.up_tags, &S.up_idx, &S.up_vals, &S.wtags, &S.wlisted, &S.wcount}) b->release();
+    msm_job_destroy(S.job_w1); msm_job_destroy(S.job_w2); msm_job_destroy(S.job_h);
+    S.job_w1 = S.job_w2 = S.job_h = nullptr;
+    for (OnesSum *o : {&S.ones_a, &S.ones_b1, &S.ones_l, &S.ones_b2}) o->release();
     if (S.stream) (void)hipStreamDestroy(S.stream);
     S.stream = nullptr;
     if (S.ev_ok) for (auto &e : S.ev) (void)hipEventDestroy(e);
@@ -304,9 +310,23 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     const size_t n = crs->n, l = crs->l, m = crs->m;
     bool ok = upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
               upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
-    ok = ok && upload(crs->A_query, pk->A_query, (n + 1) * 64) == 0 && upload(crs->B_g1, pk->B_g1, (n + 1) * 64) == 0 &&
-         upload(crs->B_g2, pk->B_g2, (n + 1) * 128) == 0 && upload(crs->H_query, pk->H_query, (m - 1) * 64) == 0 &&
-         upload(crs->L_query, pk->L_query, (n - l) * 64) == 0;
+    if (ok) {
+        // the queries become per-window tables (level 0 is the query as uploaded).  A, B_g1, B_g2 and L are indexed by the same witness and
+        // share one digit sort per proof, so they share one window size; H has its own.
+        static const char *cw = getenv("ZKG_TABLE_C_W"), *ch = getenv("ZKG_TABLE_C_H");                  // tuning aids
+        const int c_w = cw ? atoi(cw) : table_window_bits(n + 1), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
+        DevBuf stage;
+        auto table = [&](WindowTable &t, const uint64_t *src, size_t count, bool g2, int c) {
+            const size_t bytes = count * (g2 ? 128 : 64);
+            if (upload(stage, src, bytes)) return false;
+            int rc = g2 ? window_table_build_g2(t, stage.as<G2Affine>(), count, c, nullptr) : window_table_build_g1(t, stage.as<G1Affine>(), count, c, nullptr);
+            return rc == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);              // `stage` is reused by the next query
+        };
+        ok = c_w >= 2 && c_w <= 16 && c_h >= 2 && c_h <= 16 &&
+             table(crs->A_query, pk->A_query, n + 1, false, c_w) && table(crs->B_g1, pk->B_g1, n + 1, false, c_w) && table(crs->B_g2, pk->B_g2, n + 1, true, c_w) &&
+             table(crs->L_query, pk->L_query, n - l, false, c_w) && table(crs->H_query, pk->H_query, m - 1, false, c_h);
+        stage.release();
+    }
     if (ok) {                                                                // rows left to the wavefront-per-row kernel
         std::vector<uint32_t> lr;
         const uint32_t *rps[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr};
@@ -334,8 +354,9 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
-                      &crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query, &crs->coset_over_m, &crs->long_rows})
+                      &crs->coset_over_m, &crs->long_rows})
         b->release();
+    for (WindowTable *t : {&crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query}) t->release();
     for (ProverSlot &S : crs->slot) slot_destroy(S);
     delete crs;
 }
@@ -360,45 +381,66 @@ static const bool g_dbg_timing = getenv("ZKG_DEBUG_TIMING") != nullptr, g_serial
 static void lap(const ProverSlot &S, const char *what) {
     if (g_dbg_timing) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
 }
-struct MsmLaunch { MsmJob *job; const G1Affine *g1; const G2Affine *g2; const uint32_t *sc; size_t cnt; int wait_ev, ev0; };
-static void slot_launches(const zkg_crs *crs, const ProverSlot &S, MsmLaunch out[5]) {
-    const size_t n = crs->n, l = crs->l, m = crs->m;
-    const uint32_t *z = S.z.as<uint32_t>();
-    // A / B_g1 / B_g2 and L only need z (event 0); H needs the NTT pipeline (event 2).  Scalars are Montgomery Fr on device.
-    const MsmLaunch L[5] = {
-        {S.job_b2, nullptr, crs->B_g2.as<G2Affine>(), z, n + 1, 0, 3},                  // the G2 MSM is the long pole: first
-        {S.job_a, crs->A_query.as<G1Affine>(), nullptr, z, n + 1, 0, 5},
-        {S.job_b1, crs->B_g1.as<G1Affine>(), nullptr, z, n + 1, 0, 7},
-        {S.job_l, crs->L_query.as<G1Affine>(), nullptr, z + 8 * (l + 1), n - l, 0, 9},
-        {S.job_h, crs->H_query.as<G1Affine>(), nullptr, S.aABC.as<uint32_t>(), m - 1, 2, 11}};
-    for (int i = 0; i < 5; ++i) out[i] = L[i];
-}
+static MsmBases table_set(const WindowTable &t, uint32_t index_sub) { MsmBases b; b.p = t.buf.p; b.g2 = t.g2; b.level_stride = t.n; b.index_sub = index_sub; return b; }
+// event slots: 0 witness resident + split done, 1 mat-vec done, 2 H coefficients done, 3 satisfiability flag landed,
+//              4-5 G1 witness job, 6-7 G2 witness job, 8-9 H job
 static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness, const uint64_t r_[4], const uint64_t s_[4], bool check) {
     S.t0 = std::chrono::steady_clock::now();
     S.check = check; memcpy(S.r.v, r_, 32); memcpy(S.s.v, s_, 32);
-    *S.flag_host = 0;
+    S.flag_host[0] = 0; S.flag_host[1] = 0;
     if (compute_h(crs, S, witness, check)) return ZKG_ERROR;
     lap(S, "h pipeline enqueued");
-    MsmLaunch launches[5]; slot_launches(crs, S, launches);
-    for (const MsmLaunch &L : launches) {                                    // concurrently, each on its own stream
-        hipStream_t js = msm_job_stream(L.job);
-        ZK_HIP(hipStreamWaitEvent(js, S.ev[L.wait_ev], 0));
-        (void)hipEventRecord(S.ev[L.ev0], js);
-        if (msm_job_launch(L.job, L.g1 ? &L.g1 : nullptr, L.g1 ? 1 : 0, L.g2, L.sc, L.cnt, true)) return ZKG_ERROR;
-        (void)hipEventRecord(S.ev[L.ev0 + 1], js);
-        if (g_serial_msm) (void)hipStreamSynchronize(js);                   // profiling aid: one multi-exponentiation at a time
+    const size_t n = crs->n, l = crs->l, m = crs->m;
+    // H: uniformly random scalars, needs the NTT pipeline (event 2)
+    {
+        hipStream_t js = msm_job_stream(S.job_h);
+        ZK_HIP(hipStreamWaitEvent(js, S.ev[2], 0));
+        (void)hipEventRecord(S.ev[8], js);
+        const MsmBases h = table_set(crs->H_query, 0);
+        if (msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true)) return ZKG_ERROR;
+        (void)hipEventRecord(S.ev[9], js);
+        if (g_serial_msm) (void)hipStreamSynchronize(js);
+    }
+    // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — ~3 % of a credential's
+    // witness — through the bucket method as a gathered subset.  The count of "the rest" sizes the launch, so the host reads it back
+    // here, after everything that does not depend on it is queued.
+    ZK_HIP(hipEventSynchronize(S.ev[0]));
+    const size_t listed = S.flag_host[1];
+    if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
+    lap(S, "witness split read back");
+    const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
+    {
+        hipStream_t js = msm_job_stream(S.job_w2);                             // G2 first: the longest chain
+        ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+        (void)hipEventRecord(S.ev[6], js);
+        if (ones_sum_launch_g2(S.ones_b2, crs->B_g2.buf.as<G2Affine>(), tags, n + 1, 0, js)) return ZKG_ERROR;
+        const MsmBases b2 = table_set(crs->B_g2, 0);
+        if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
+        (void)hipEventRecord(S.ev[7], js);
+        if (g_serial_msm) (void)hipStreamSynchronize(js);
+    }
+    {
+        hipStream_t js = msm_job_stream(S.job_w1);
+        ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+        (void)hipEventRecord(S.ev[4], js);
+        if (ones_sum_launch_g1(S.ones_a, crs->A_query.buf.as<G1Affine>(), tags, n + 1, 0, js) ||
+            ones_sum_launch_g1(S.ones_b1, crs->B_g1.buf.as<G1Affine>(), tags, n + 1, 0, js) ||
+            ones_sum_launch_g1(S.ones_l, crs->L_query.buf.as<G1Affine>(), tags, n + 1, (uint32_t)(l + 1), js)) return ZKG_ERROR;
+        const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))};
+        if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
+        (void)hipEventRecord(S.ev[5], js);
+        if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
     lap(S, "msm jobs enqueued");
     return ZKG_OK;
 }
-static void slot_drain(const zkg_crs *crs, ProverSlot &S) {                  // after an error: nothing of this slot may still be running
-    MsmLaunch launches[5]; slot_launches(crs, S, launches);
+static void slot_drain(const zkg_crs *, ProverSlot &S) {                      // after an error: nothing of this slot may still be running
     (void)hipStreamSynchronize(S.stream);
-    for (const MsmLaunch &L : launches) (void)hipStreamSynchronize(msm_job_stream(L.job));
+    for (MsmJob *j : {S.job_w1, S.job_w2, S.job_h}) if (j) (void)hipStreamSynchronize(msm_job_stream(j));
 }
 static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t *proof_len) {
     hipStream_t s = S.stream;
-    G1 AB[2]; G2 Bt2; G1 Ht, Lt;
+    G1 W1[3]; G2 Bt2; G1 Ht;
     // host work that needs only the CRS and (r, s): overlaps the GPU
     uint32_t rc[8], sc[8], rsc[8];
     canonical_limbs(S.r, rc); canonical_limbs(S.s, sc); canonical_limbs(S.r * S.s, rsc);
@@ -408,37 +450,38 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     G2 s_delta2 = delta2.mul(sc, 8);
     lap(S, "crs-only host products");
     if (S.check) {
-        ZK_HIP(hipStreamSynchronize(s));
-        if (*S.flag_host) {                                                  // drain the speculative MSMs, then refuse like snark.cpp:121-124
+        ZK_HIP(hipEventSynchronize(S.ev[3]));
+        if (S.flag_host[0]) {                                                // drain the speculative MSMs, then refuse like snark.cpp:121-124
             slot_drain(crs, S);
             set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
         }
     }
-    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing.
-    //      A and B_g1 end early: s*A + r*B_1 - rs*delta (two 254-bit scalar multiplications, ~0.2 ms) is formed while H is still on
-    //      the GPU; B_g2's host tail (chunk sums and 255 G2 doublings, ~0.3 ms) runs on a helper thread.
-    auto g2_tail = std::async(std::launch::async, [&] { return msm_job_finish(S.job_b2, nullptr, &Bt2); });
-    if (msm_job_finish(S.job_a, &AB[0], nullptr) || msm_job_finish(S.job_b1, &AB[1], nullptr)) { (void)g2_tail.get(); slot_drain(crs, S); return ZKG_ERROR; }
-    G1 gA = alpha; gA.add(AB[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
-    G1 gB1 = beta1; gB1.add(AB[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
+    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing: the
+    //      witness queries end early, so s*A + r*B_1 - rs*delta (two 254-bit scalar multiplications) is formed while H is still running
+    if (msm_job_finish(S.job_w1, W1, nullptr)) { slot_drain(crs, S); return ZKG_ERROR; }
+    W1[0].add(*reinterpret_cast<const G1 *>(S.ones_a.host)); W1[1].add(*reinterpret_cast<const G1 *>(S.ones_b1.host)); W1[2].add(*reinterpret_cast<const G1 *>(S.ones_l.host));
+    G1 gA = alpha; gA.add(W1[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
+    G1 gB1 = beta1; gB1.add(W1[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
     G1 gC = gA.mul(sc, 8); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
-    lap(S, "s*A + r*B1 - rs*delta");
-    if (msm_job_finish(S.job_l, &Lt, nullptr) || msm_job_finish(S.job_h, &Ht, nullptr)) { (void)g2_tail.get(); slot_drain(crs, S); return ZKG_ERROR; }
-    gC.add(Lt); gC.add(Ht);                                                 // C = H_t + L_t + s A + r B_1 - rs delta
-    lap(S, "G1 side assembled");
-    if (g2_tail.get()) { slot_drain(crs, S); return ZKG_ERROR; }
-    lap(S, "G2 msm finished");
+    gC.add(W1[2]);
+    lap(S, "s*A + r*B1 - rs*delta + L");
+    if (msm_job_finish(S.job_w2, nullptr, &Bt2)) { slot_drain(crs, S); return ZKG_ERROR; }
+    Bt2.add(*reinterpret_cast<const G2 *>(S.ones_b2.host));
     G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
     size_t off = 0;
-    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2); off += ser_g1(proof_out + off, gC);
+    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2);
+    lap(S, "A, B serialised");
+    if (msm_job_finish(S.job_h, &Ht, nullptr)) { slot_drain(crs, S); return ZKG_ERROR; }
+    gC.add(Ht);                                                             // C = H_t + L_t + s A + r B_1 - rs delta
+    off += ser_g1(proof_out + off, gC);
     *proof_len = off;
     lap(S, "assembled+serialised");
     ZK_HIP(hipStreamSynchronize(s));
     {
         float t;
         auto el = [&](int a, int b) { return hipEventElapsedTime(&t, S.ev[a], S.ev[b]) == hipSuccess ? t : -1.f; };
-        S.stage_ms[0] = el(0, 1); S.stage_ms[1] = el(1, 2); S.stage_ms[2] = el(5, 6); S.stage_ms[3] = el(7, 8); S.stage_ms[4] = el(3, 4);
-        S.stage_ms[5] = el(11, 12); S.stage_ms[6] = el(9, 10);
+        S.stage_ms[0] = el(0, 1); S.stage_ms[1] = el(1, 2); S.stage_ms[2] = el(4, 5); S.stage_ms[3] = 0.f; S.stage_ms[4] = el(6, 7);
+        S.stage_ms[5] = el(8, 9); S.stage_ms[6] = 0.f;
         S.stage_ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count();
         for (int i = 0; i < 8; ++i) crs->stage_ms[i] = S.stage_ms[i];
     }
