@@ -14,5 +14,16 @@ w = ck.witness()
 kp = zkg.Keypair(ck.r1cs, bench.splitmix_fr(5, 77))
 crs = zkg.Crs(kp.pk)
 rs = bench.splitmix_fr(2, 9)
-for _ in range(10):
-    t = time.perf_counter(); rc, proof = crs.prove(w, rs[0], rs[1]); print(rc, round((time.perf_counter() - t) * 1e3, 3), "ms", [round(x, 3) for x in crs.stage_ms()])
+import numpy as np
+reps = int(os.environ.get("REPS", "10"))
+ts = []
+for _ in range(reps):
+    t = time.perf_counter(); rc, proof = crs.prove(w, rs[0], rs[1]); ts.append((time.perf_counter() - t) * 1e3)
+    if reps <= 10:
+        print(rc, round(ts[-1], 3), "ms", [round(x, 3) for x in crs.stage_ms()])
+tags, fidx, fvals = ck.sparse_witness()
+tsp = []
+for _ in range(reps):
+    t = time.perf_counter(); rc2, proof2 = crs.prove_sparse(tags, fidx, fvals, rs[0], rs[1]); tsp.append((time.perf_counter() - t) * 1e3)
+assert rc == 0 and rc2 == 0 and proof2 == proof
+print(f"k={k} ZKG_PRIO={os.environ.get('ZKG_PRIO')} dense median {np.median(ts[2:]):.3f} min {min(ts):.3f} | sparse median {np.median(tsp[2:]):.3f} min {min(tsp):.3f} ms | stages", [round(x, 3) for x in crs.stage_ms()])

@@ -111,9 +111,13 @@ int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);   // out_g1[k]: k-th G1
 // the multi_exp_with_mixed_addition split of a witness z = [1 | w] (n1 elements, Montgomery): tags (0 zero, 1 one, 2 other), the
 // indices of the others and their count; and the flat sum of the bases tagged one (result lands in pinned host memory)
 int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s);
-struct OnesSum { DevBuf partials; void *host = nullptr; bool g2 = false; void release(); };
-int ones_sum_launch_g1(OnesSum &o, const G1Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s);
-int ones_sum_launch_g2(OnesSum &o, const G2Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s);
+struct OnesSum {                                            // results: nsets points (G1 or G2, XYZZ) back to back in pinned host memory
+    DevBuf partials; void *host = nullptr; bool g2 = false; int nsets = 0; void release();
+    const G1 &g1(int i) const { return reinterpret_cast<const G1 *>(host)[i]; }
+    const G2 &g2pt(int i) const { return reinterpret_cast<const G2 *>(host)[i]; }
+};
+// level 0 of each set (its plain bases) and its index_sub are read; all sets of one field
+int ones_sum_launch(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *d_tags, size_t n1, hipStream_t s);
 // scalars: n x 8 u32 (canonical, or Montgomery when scalars_mont).  Zero scalars are dropped and ones land in
 // one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s, bool mostly_bits = false);

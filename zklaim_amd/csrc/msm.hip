@@ -52,7 +52,7 @@ static constexpr size_t RED_LARGE_BUCKETS = (size_t)1 << 18;
 static constexpr int MAX_C = 16;             // LDS histogram: 2^(c-1) u32 counters <= 128 KiB
 static constexpr uint32_t HEAVY_S = 512;     // entries per heavy part (one wavefront sums one part)
 static constexpr uint32_t HEAVY_T_MAX = 1024;
-static constexpr int HEAVY_PART_BLOCKS = 1024, HEAVY_MERGE_BLOCKS = 256;
+static constexpr int HEAVY_PART_BLOCKS = 512, HEAVY_MERGE_BLOCKS = 128;
 static constexpr int SORT_THREADS = 1024;
 static constexpr int SCAN_ITEMS = 4;         // per thread in the block scan
 
@@ -64,6 +64,9 @@ struct MsmGeom { uint32_t c, W, B, Wt, w0, ws; };
 // the W bucket sets are summed bucket-wise (k_bucket_fold) and reduced ONCE, and no doubling is left for the host.  `gather`: the scalars
 // were a gathered subset (a witness' non-bit values); entry i stands for element gather[i] of the set.  `index_sub`: the set starts at
 // that element (the L query starts behind the public inputs); entries below it belong to no base of this set.
+// The base sets of one field in a launch are batched: every kernel below runs once for all of them, blockIdx.y = set, each set with its
+// own accumulators, heavy lists and results laid out `set` strides apart (SetLayout), all walking the same sorted digit list.
+struct SetLayout { size_t buckets, items, heavy, partials, folded, red_out; };     // elements per set in each per-set array
 template <class F> struct BaseView {
     const Affine<F> *p; size_t level_stride; const uint32_t *gather; uint32_t index_sub, B;
     ZK_D Affine<F> load(uint32_t e, size_t gb) const {
@@ -73,7 +76,8 @@ template <class F> struct BaseView {
         return p[(level_stride ? (gb / B) * level_stride : 0) + (i - index_sub)];
     }
 };
-struct HeavyItem { uint32_t start, end, gb; };   // a part: range of the sorted index list, and the bucket it belongs to
+template <class F> struct ViewSet { BaseView<F> v[MSM_MAX_SETS]; };
+struct HeavyItem { uint32_t start, end, gb, single; };   // a part: range of the sorted index list, the bucket it belongs to, and whether it is that bucket's only part
 struct HeavyBucket { uint32_t gb, first_item, nparts; };
 
 // Window size.  Measured on MI355X with uniformly random scalars (tools/msm_c_sweep.py): the accumulation runs one lane per
@@ -382,10 +386,13 @@ __global__ __launch_bounds__(1024) void k_rx_fine_big(const uint32_t *tmp, uint3
 // windows and stays on the lane-per-bucket path; a sparse bit-witness MSM gets a small threshold and a short tail).
 ZK_D uint32_t heavy_threshold_dev(const uint32_t *offsets, size_t total_buckets, uint32_t divisor) {
     uint32_t entries = offsets[total_buckets];
-    uint32_t t = (uint32_t)(4 * (uint64_t)entries / total_buckets) + 32;
+    // the slack shrinks with the average: a sparse launch (a witness' few non-bit scalars over 2^19 buckets) is pure latency, and its
+    // longest lane-walked list is its duration
+    uint32_t avg6 = (uint32_t)(6 * (uint64_t)entries / total_buckets), slack = 8 + avg6 > 32 ? 32 : 8 + avg6;
+    uint32_t t = (uint32_t)(4 * (uint64_t)entries / total_buckets) + slack;
     t = t > HEAVY_T_MAX ? HEAVY_T_MAX : t;
     t /= divisor;
-    return t < 16 ? 16 : t;
+    return t < 4 ? 4 : t;
 }
 
 // ---- 5. bucket order by descending length (classes 0..heavy_t, heavy_t+1 = heavy) ------------------------
@@ -423,19 +430,23 @@ __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, co
 
 // ---- 6. bucket accumulation (dominant kernel) -------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_accum(const BaseView<F> bases, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
-                                                       size_t total_buckets, XYZZ<F> *buckets,
-                                                       HeavyItem *items, HeavyBucket *heavy, uint32_t *counters /* [0] items, [1] heavy buckets */) {
+__global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+                                                       size_t lanes /* <= total buckets: the first `lanes` entries of order */, XYZZ<F> *buckets, HeavyItem *items,
+                                                       HeavyBucket *heavy, uint32_t *counters /* per set: [0] items, [1] heavy buckets */, SetLayout L) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= total_buckets) return;
+    if (tid >= lanes) return;
+    const size_t total_buckets = L.buckets;
+    const uint32_t set = blockIdx.y;
+    const BaseView<F> bases = views.v[set];
+    buckets += set * L.buckets; items += set * L.items; heavy += set * L.heavy; counters += 2 * set;
     const uint32_t heavy_t = heavy_threshold_dev(offsets, total_buckets, sizeof(F) > sizeof(Fq) ? 3 : 1);   // a G2 addition costs ~3x a G1 addition
     const uint32_t gb = order[tid];
     uint32_t k = offsets[gb], end = offsets[gb + 1];
     if (end - k > heavy_t) {
         uint32_t nparts = (end - k + HEAVY_S - 1) / HEAVY_S;
         uint32_t first = atomicAdd(&counters[0], nparts);
-        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb}; }
-        heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
+        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb, nparts == 1}; }
+        if (nparts > 1) heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};                   // a single part writes its bucket itself
         return;
     }
     XYZZ<F> acc = XYZZ<F>::inf();
@@ -470,11 +481,14 @@ ZK_D void lds_tree_reduce(XYZZ<F> *seg, uint32_t n, uint32_t tid, uint32_t nthre
 
 // one wavefront per heavy part: 64 lanes stride over <= HEAVY_S entries, then a 6-level LDS tree
 template <class F>
-__global__ __launch_bounds__(256) void k_heavy_parts(const BaseView<F> bases, const uint32_t *sorted, const HeavyItem *items,
-                                                      const uint32_t *counters, XYZZ<F> *partials) {
+__global__ __launch_bounds__(256) void k_heavy_parts(const ViewSet<F> views, const uint32_t *sorted, const HeavyItem *items,
+                                                      const uint32_t *counters, XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
-    const uint32_t n_items = counters[0], t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t set = blockIdx.y;
+    const BaseView<F> bases = views.v[set];
+    items += set * L.items; partials += set * L.partials; buckets += set * L.buckets;
+    const uint32_t n_items = counters[2 * set], t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (uint32_t base = blockIdx.x * 4; base < n_items; base += gridDim.x * 4) {      // uniform trip count per workgroup
         uint32_t it = base + wv;
         XYZZ<F> acc = XYZZ<F>::inf();
@@ -490,17 +504,19 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const BaseView<F> bases, co
         sh[t] = acc;
         __syncthreads();
         lds_tree_reduce<F>(sh + wv * 64, 64, lane, 64, [] { __syncthreads(); });      // the four wavefronts run their trees in step
-        if (lane == 0 && it < n_items) partials[it] = sh[t].normalized();
+        if (lane == 0 && it < n_items) { if (items[it].single) buckets[items[it].gb] = sh[t].normalized(); else partials[it] = sh[t].normalized(); }
         __syncthreads();
     }
 }
 
 // one workgroup per heavy bucket: strided sum of its parts' partials, LDS tree, write the bucket
 template <class F>
-__global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, const uint32_t *counters, const XYZZ<F> *partials, XYZZ<F> *buckets) {
+__global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, const uint32_t *counters, const XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
-    const uint32_t n_heavy = counters[1], t = threadIdx.x;
+    const uint32_t set = blockIdx.y;
+    heavy += set * L.heavy; partials += set * L.partials; buckets += set * L.buckets;
+    const uint32_t n_heavy = counters[2 * set + 1], t = threadIdx.x;
     for (uint32_t hb = blockIdx.x; hb < n_heavy; hb += gridDim.x) {
         HeavyBucket h = heavy[hb];
         XYZZ<F> acc = XYZZ<F>::inf();
@@ -518,13 +534,15 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
 //      dependency chain of 2(L-1) + 2 log2(LANES) + 2 additions, and the quad turns each addition's 14 dependent
 //      multiplications into 4 rounds.
 template <class F, int RED_L_LOG>
-__global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out) {
+__global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZZ<F> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<F> *out,
+                                                                       size_t in_set_stride, size_t out_set_stride) {
     constexpr int RED_LANES = RedGeom<F>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);              // 2 * RED_LANES points
     const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;          // logical lane, position in its quad
     const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
-    const XYZZ<F> *X = buckets + (size_t)w * B;
+    const XYZZ<F> *X = buckets + blockIdx.y * in_set_stride + (size_t)w * B;
+    out += blockIdx.y * out_set_stride;
     const uint32_t base = ch * RED_CHUNK + t * RED_L;
     // lane-local running sums: S = sum_j X_j, T0 = sum_j j*X_j
     XYZZ<F> run = XYZZ<F>::inf(), T0 = XYZZ<F>::inf();
@@ -565,14 +583,31 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
 }
 
 // ---- 7b. per-window tables: all W windows weigh the same, so their bucket sets are summed bucket-wise before the one reduction.
-//      One DPP quad per bucket walks the W accumulators (most are infinity for a sparse witness: xyzz_add_quad returns at once).
+//      A workgroup takes FOLD_B buckets: its 256 threads load one accumulator each (window-major, so a wavefront reads FOLD_B
+//      consecutive buckets of one window), then an LDS tree over the windows — ceil(log2 W) levels instead of a W-long chain, the upper
+//      levels shared by DPP quads.  Empty accumulators (a sparse witness) cost nothing: additions with infinity return at once.
+static constexpr uint32_t FOLD_THREADS = 256;
 template <class F>
-__global__ __launch_bounds__(256) void k_bucket_fold(const XYZZ<F> *buckets, uint32_t W, uint32_t B, XYZZ<F> *out) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid >> 2, q = gid & 3;
-    if (b >= B) return;
-    XYZZ<F> acc = buckets[b];
-    for (uint32_t w = 1; w < W; ++w) xyzz_add_quad(acc, buckets[(size_t)w * B + b], q);
-    if (q == 0) out[b] = acc.normalized();
+__global__ __launch_bounds__(FOLD_THREADS) void k_bucket_fold(const XYZZ<F> *buckets, const uint32_t *counts, uint32_t W, uint32_t B, uint32_t fold_b_log, XYZZ<F> *out, SetLayout L) {
+    extern __shared__ unsigned char red_smem[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // FOLD_THREADS points: [window slot][bucket]
+    const uint32_t t = threadIdx.x, FB = 1u << fold_b_log, slots = FOLD_THREADS >> fold_b_log;     // window slots held at once (a power of two)
+    const uint32_t bl = t & (FB - 1), slot = t >> fold_b_log, b = blockIdx.x * FB + bl;
+    buckets += blockIdx.y * L.buckets; out += blockIdx.y * L.folded;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    // buckets without entries were never written (the accumulation is launched over the non-empty ones only): their length says so
+    if (b < B) for (uint32_t w = slot; w < W; w += slots) if (counts[(size_t)w * B + b]) acc.add(buckets[(size_t)w * B + b]);   // W <= slots for the shipped window sizes: no addition
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = slots / 2; d >= 1; d >>= 1) {                    // tree over the window slots; pairs (slot, slot + d) of the same bucket
+        const uint32_t pairs = d << fold_b_log;
+        if (4 * pairs <= FOLD_THREADS) {
+            const uint32_t u = t >> 2, q = t & 3;
+            if (u < pairs) { XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + pairs], q); if (q == 0) sh[u] = a; }
+        } else if (t < pairs) { XYZZ<F> a = sh[t]; a.add(sh[t + pairs]); sh[t] = a; }
+        __syncthreads();
+    }
+    if (t < FB && b < B) out[b] = sh[t].normalized();
 }
 
 // level j+1 of a window table from level j: out_i = 2^c in_i (c doublings in XYZZ, one inversion back to affine)
@@ -613,9 +648,11 @@ __global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_
     if (tag == 2) listed[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint32_t)i;
 }
 template <class F>
-__global__ __launch_bounds__(256) void k_ones_sum(const Affine<F> *bases, const uint8_t *tags, size_t n1, uint32_t index_sub, XYZZ<F> *partials) {
+__global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const uint8_t *tags, size_t n1, XYZZ<F> *partials) {
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
+    const Affine<F> *bases = views.v[blockIdx.y].p; const uint32_t index_sub = views.v[blockIdx.y].index_sub;
+    partials += (size_t)blockIdx.y * (gridDim.x + 1);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride)
@@ -626,9 +663,10 @@ __global__ __launch_bounds__(256) void k_ones_sum(const Affine<F> *bases, const 
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0].normalized();
 }
 template <class F>
-__global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F> *partials, uint32_t count, XYZZ<F> *out) {
+__global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uint32_t count) {        // per set: partials[0..count) -> partials[count]
     extern __shared__ unsigned char red_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
+    XYZZ<F> *partials = partials_all + (size_t)blockIdx.x * (count + 1), *out = partials + count;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t i = threadIdx.x; i < count; i += 256) acc.add(partials[i]);
     sh[threadIdx.x] = acc;
@@ -638,10 +676,11 @@ __global__ __launch_bounds__(256) void k_sum_partials(const XYZZ<F> *partials, u
 }
 
 // ---- jobs: one MSM (or several base sets over one scalar vector) in flight on one stream ---------------------
-struct MsmSlot {                    // per base set: accumulators and the host landing zone of its chunk results
+struct MsmGroup {                   // the base sets of one field in a launch: accumulators and the host landing zone of their chunk results
     DevBuf buckets, folded, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
-    void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false;
-    uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
+    void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false; int nsets = 0;
+    int out_index[MSM_MAX_SETS] = {0};                 // position of each set among the launch's sets of this field
+    uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry per set: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
     int host_reserve(size_t bytes) {
         if (bytes <= host_cap) return 0;
         if (host_red) (void)hipHostFree(host_red);
@@ -659,8 +698,8 @@ struct MsmSlot {                    // per base set: accumulators and the host l
 struct MsmJob {
     hipStream_t stream = nullptr; bool own_stream = false;
     DevBuf digits, hist, counts, offsets, scan_sums, class_hist, order, sorted, rx_tmp, rx_meta;
-    MsmSlot slot[MSM_MAX_SETS]; int nslots = 0;
-    MsmGeom g{}; size_t n = 0; int red_l_log = RED_L_LOG_SMALL;
+    MsmGroup group[2];                 // [0] the G1 sets, [1] the G2 sets of the launch
+    MsmGeom g{}; size_t n = 0;
     int window_hint = 0;               // 0: pick_geom's rule
     bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
@@ -669,55 +708,67 @@ struct MsmJob {
 };
 
 template <class F>
-static int launch_accumulate(MsmJob *job, MsmSlot &sl, const MsmBases &set, const uint32_t *d_gather, bool time_it) {
-    const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B;
+static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, const uint32_t *d_gather, bool time_it) {
+    const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B; const unsigned ns = (unsigned)gr.nsets;
     hipStream_t s = job->stream;
     size_t n_entries_max = n * g.W;
-    size_t max_heavy = n_entries_max / 16 + 1, max_items = n_entries_max / HEAVY_S + max_heavy + 1;     // worst case of the device-side threshold
-    if (sl.heavy_items.reserve(max_items * sizeof(HeavyItem)) || sl.heavy_buckets.reserve(max_heavy * sizeof(HeavyBucket)) ||
-        sl.heavy_counters.reserve(8) || sl.heavy_partials.reserve(max_items * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    ZK_HIP(hipMemsetAsync(sl.heavy_counters.p, 0, 8, s));
+    size_t max_heavy = n_entries_max / 4 + 1, max_items = n_entries_max / 4 + n_entries_max / HEAVY_S + 2;     // worst case of the device-side threshold (>= 4)
     typedef RedGeom<F> RG;
-    sl.table = set.level_stride != 0;
-    sl.red_windows = sl.table ? 1 : g.W;                             // a table's windows are folded into one bucket set first
-    int red_l_log = (size_t)sl.red_windows * g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
-    sl.chunk_log = RG::LANES_LOG + red_l_log;
-    sl.cpw = (g.B + (1u << sl.chunk_log) - 1) >> sl.chunk_log; sl.nred = (size_t)sl.red_windows * sl.cpw;
-    if (sl.buckets.reserve(total_buckets * sizeof(XYZZ<F>)) || sl.red_out.reserve(sl.nred * 2 * sizeof(XYZZ<F>)) ||
-        (sl.table && sl.folded.reserve((size_t)g.B * sizeof(XYZZ<F>))) || sl.host_reserve(sl.nred * 2 * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    XYZZ<F> *buckets = sl.buckets.as<XYZZ<F>>();
-    const BaseView<F> view{reinterpret_cast<const Affine<F> *>(set.p), set.level_stride, d_gather, set.index_sub, g.B};
+    gr.table = sets[0].level_stride != 0;
+    gr.red_windows = gr.table ? 1 : g.W;                             // a table's windows are folded into one bucket set first
+    const int red_l_log = (size_t)gr.red_windows * g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
+    gr.chunk_log = RG::LANES_LOG + red_l_log;
+    gr.cpw = (g.B + (1u << gr.chunk_log) - 1) >> gr.chunk_log; gr.nred = (size_t)gr.red_windows * gr.cpw;
+    SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 2;
+    if (gr.heavy_items.reserve(ns * max_items * sizeof(HeavyItem)) || gr.heavy_buckets.reserve(ns * max_heavy * sizeof(HeavyBucket)) ||
+        gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
+        gr.buckets.reserve(ns * total_buckets * sizeof(XYZZ<F>)) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
+        (gr.table && gr.folded.reserve(ns * (size_t)g.B * sizeof(XYZZ<F>))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    ZK_HIP(hipMemsetAsync(gr.heavy_counters.p, 0, 8 * MSM_MAX_SETS, s));
+    XYZZ<F> *buckets = gr.buckets.as<XYZZ<F>>();
+    ViewSet<F> views;
+    for (unsigned i = 0; i < (unsigned)MSM_MAX_SETS; ++i) {
+        const MsmBases &b = sets[i < ns ? i : 0];
+        views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), b.level_stride, d_gather, b.index_sub, g.B};
+    }
+    // `order` lists the buckets by descending length, the empty ones last.  A table launch folds through the bucket lengths and never reads
+    // an empty bucket, so its accumulation covers at most one lane per entry: a witness' ~10^5 entries over 2^19 buckets would otherwise
+    // dispatch 8 K wavefronts that find nothing to do — on a chip they share with the H multi-exponentiation.
+    const size_t lanes = gr.table ? std::min(total_buckets, n_entries_max) : total_buckets;
     if (time_it) g_dominant_timer.begin(s);
-    hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s,
-                       view, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), total_buckets, buckets,
-                       sl.heavy_items.as<HeavyItem>(), sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
+                       views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
+                       gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     if (time_it) g_dominant_timer.end(s);
-    hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       view, job->sorted.as<uint32_t>(), sl.heavy_items.as<HeavyItem>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>());
-    hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS), dim3(256), 256 * sizeof(XYZZ<F>), s,
-                       sl.heavy_buckets.as<HeavyBucket>(), sl.heavy_counters.as<uint32_t>(), sl.heavy_partials.as<XYZZ<F>>(), buckets);
-    const XYZZ<F> *red_in = buckets;
-    if (sl.table) {
-        hipLaunchKernelGGL(k_bucket_fold<F>, dim3((unsigned)((4 * (size_t)g.B + 255) / 256)), dim3(256), 0, s, buckets, g.W, g.B, sl.folded.as<XYZZ<F>>());
-        red_in = sl.folded.as<XYZZ<F>>();
+    hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(XYZZ<F>), s,
+                       views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
+    hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS, ns), dim3(256), 256 * sizeof(XYZZ<F>), s,
+                       gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
+    const XYZZ<F> *red_in = buckets; size_t in_stride = L.buckets;
+    if (gr.table) {
+        uint32_t slots = 1; while (slots < g.W && slots < 32) slots <<= 1;                // window slots per workgroup: W rounded up to a power of two (<= 32)
+        uint32_t fold_b_log = 0; while ((FOLD_THREADS >> (fold_b_log + 1)) >= slots) ++fold_b_log;
+        hipLaunchKernelGGL(k_bucket_fold<F>, dim3((g.B + (1u << fold_b_log) - 1) >> fold_b_log, ns), dim3(FOLD_THREADS), FOLD_THREADS * sizeof(XYZZ<F>), s,
+                           buckets, job->counts.as<uint32_t>(), g.W, g.B, fold_b_log, gr.folded.as<XYZZ<F>>(), L);
+        red_in = gr.folded.as<XYZZ<F>>(); in_stride = L.folded;
     }
     if (red_l_log == RED_L_LOG_LARGE)
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
-                           red_in, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+                           red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     else
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)sl.nred), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
-                           red_in, g.B, sl.cpw, sl.red_out.as<XYZZ<F>>());
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+                           red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
-    ZK_HIP(hipMemcpyAsync(sl.host_red, sl.red_out.p, sl.nred * 2 * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+    ZK_HIP(hipMemcpyAsync(gr.host_red, gr.red_out.p, ns * L.red_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
     return ZKG_OK;
 }
 
 // host: window value V_w = sum_b (b+1) X_b = U_w + P_w, with chunk ch contributing U_ch + (ch*RED_CHUNK) * P_ch to U_w
-// and P_ch to P_w; then Horner over windows (c doublings each).  A table slot arrives as ONE window of weight 1: no doublings at all.
+// and P_ch to P_w; then Horner over windows (c doublings each).  A table set arrives as ONE window of weight 1: no doublings at all.
 template <class F>
-static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
-    const MsmGeom g = job->g; const uint32_t cpw = sl.cpw, W = sl.red_windows;
-    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(sl.host_red);
+static XYZZ<F> host_combine(const MsmJob *job, const MsmGroup &gr, int set) {
+    const MsmGeom g = job->g; const uint32_t cpw = gr.cpw, W = gr.red_windows;
+    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(gr.host_red) + (size_t)set * gr.nred * 2;
     std::vector<XYZZ<F>> V(W);
     auto window = [&](int w) {
         XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
@@ -727,11 +778,34 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmSlot &sl) {
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
-        if (!weighted.is_inf()) for (int i = 0; i < sl.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
+        if (!weighted.is_inf()) for (int i = 0; i < gr.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
     };
-    if (W == 1) { window(0); return V[0]; }
+    if (gr.table) {                                                             // one window of weight 1; its chunks in segments on the host pool
+        const int SEG = 16, nseg = ((int)cpw + SEG - 1) / SEG;
+        if (nseg <= 1) { window(0); return V[0]; }
+        // segment s = chunks [16 s, 16 s + 16): Usum_s = sum U, Psum_s = sum P, Wt_s = sum (ch - 16 s) P_ch; then
+        // sum_ch ch P_ch = sum_s Wt_s + 16 * sum_s s Psum_s
+        std::vector<XYZZ<F>> Us(nseg), Ps(nseg), Wt(nseg);
+        host_parallel_for(nseg, [&](int sg) {
+            XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
+            const int lo = sg * SEG, hi = std::min<int>((int)cpw, lo + SEG);
+            for (int ch = hi - 1; ch >= lo; --ch) {
+                Usum.add(red[2 * (size_t)ch + 1]);
+                suffix.add(red[2 * (size_t)ch]);
+                if (ch > lo) weighted.add(suffix);
+            }
+            Us[sg] = Usum; Ps[sg] = suffix; Wt[sg] = weighted;
+        });
+        XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), seg_weighted = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
+        for (int sg = nseg - 1; sg >= 0; --sg) { Usum.add(Us[sg]); weighted.add(Wt[sg]); suffix.add(Ps[sg]); if (sg >= 1) seg_weighted.add(suffix); }
+        if (!seg_weighted.is_inf()) for (int i = 0; i < 4; ++i) seg_weighted = seg_weighted.dbl();        // * 16 chunks per segment
+        weighted.add(seg_weighted);
+        if (!weighted.is_inf()) for (int i = 0; i < gr.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
+        Usum.add(weighted); Usum.add(suffix);
+        return Usum;
+    }
     host_parallel_for((int)W, window);                                          // the windows are independent
     // sum_j 2^(c (w0 + j ws)) V_j: Horner with c*ws doublings per owned window, then the shift of the lowest one
     XYZZ<F> acc = XYZZ<F>::inf();
@@ -809,7 +883,7 @@ hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
 void msm_job_destroy(MsmJob *j) {
     if (!j) return;
     for (DevBuf *b : {&j->digits, &j->hist, &j->counts, &j->offsets, &j->scan_sums, &j->class_hist, &j->order, &j->sorted, &j->rx_tmp, &j->rx_meta}) b->release();
-    for (auto &sl : j->slot) sl.release();
+    for (auto &gr : j->group) gr.release();
     if (j->own_stream) (void)hipStreamDestroy(j->stream);
     delete j;
 }
@@ -828,30 +902,26 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
     for (int i = 0; i < nsets; ++i) if ((sets[i].level_stride != 0) != any_table) { set_error("msm: table and plain base sets cannot share a launch"); return ZKG_ERROR; }
     if (any_table && (job->w0 != 0 || job->ws != 1 || job->window_hint <= 0)) { set_error("msm: a table launch covers all windows at the table's window size"); return ZKG_ERROR; }
     job->g = pick_geom(n, job->window_hint, job->w0, job->ws); job->n = n;
-    job->nslots = nsets; job->empty = false;
-    for (int i = 0; i < nsets; ++i) job->slot[i].g2 = sets[i].g2;
+    job->empty = false;
+    MsmBases by_field[2][MSM_MAX_SETS];
+    for (MsmGroup &gr : job->group) gr.nsets = 0;
+    job->group[0].g2 = false; job->group[1].g2 = true;
+    for (int i = 0; i < nsets; ++i) { MsmGroup &gr = job->group[sets[i].g2 ? 1 : 0]; by_field[sets[i].g2 ? 1 : 0][gr.nsets] = sets[i]; gr.out_index[gr.nsets] = gr.nsets; ++gr.nsets; }
     if (job->g.W == 0 || n == 0) { job->empty = true; return ZKG_OK; }        // no point, or this rank owns no window: the identity
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
     if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return ZKG_ERROR;
     lap("sort enqueued");
-    bool timed = false;
-    for (int i = 0; i < nsets; ++i) {
-        MsmSlot &sl = job->slot[i];
-        const bool time_it = job == &g_default_job && !timed && (!sets[i].g2 || nsets == 1);
-        timed = timed || time_it;
-        if (sets[i].g2 ? launch_accumulate<Fq2>(job, sl, sets[i], d_gather, time_it) : launch_accumulate<Fq>(job, sl, sets[i], d_gather, time_it)) return ZKG_ERROR;
-    }
+    const bool timed_field_g2 = job->group[0].nsets == 0;                       // the kernel timer follows the first G1 launch (G2 when there is no G1 set)
+    if (job->group[1].nsets && launch_accumulate<Fq2>(job, job->group[1], by_field[1], d_gather, job == &g_default_job && timed_field_g2)) return ZKG_ERROR;   // G2 first: the longer chains
+    if (job->group[0].nsets && launch_accumulate<Fq>(job, job->group[0], by_field[0], d_gather, job == &g_default_job)) return ZKG_ERROR;
     lap("accum enqueued");
     return ZKG_OK;
 }
 // wait for the job's stream and finish on the host; outputs in launch order: out_g1[k] for the k-th G1 set, out_g2[k] for the k-th G2 set
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
     ZK_HIP(hipStreamSynchronize(job->stream));
-    int k1 = 0, k2 = 0;
-    for (int i = 0; i < job->nslots; ++i) {
-        if (job->slot[i].g2) out_g2[k2++] = job->empty ? G2::inf() : host_combine<Fq2>(job, job->slot[i]);
-        else out_g1[k1++] = job->empty ? G1::inf() : host_combine<Fq>(job, job->slot[i]);
-    }
+    for (int k = 0; k < job->group[0].nsets; ++k) out_g1[k] = job->empty ? G1::inf() : host_combine<Fq>(job, job->group[0], k);
+    for (int k = 0; k < job->group[1].nsets; ++k) out_g2[k] = job->empty ? G2::inf() : host_combine<Fq2>(job, job->group[1], k);
     return ZKG_OK;
 }
 
@@ -898,21 +968,28 @@ int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_list
     return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
 template <class F>
-static int ones_sum_launch_t(OnesSum &o, const Affine<F> *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) {
-    // ~4 tagged elements per lane: the sum is a dependency chain per lane, then a 8-level tree per workgroup
-    const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (n1 + 1023) / 1024));
-    o.g2 = sizeof(F) != sizeof(Fq);
-    if (o.partials.reserve((size_t)(blocks + 1) * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    if (!o.host) { if (!hip_ok(hipHostMalloc(&o.host, sizeof(G2), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return ZKG_ERROR; }
+static int ones_sum_launch_t(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *d_tags, size_t n1, hipStream_t s) {
+    // lanes stride over the tags; per workgroup an 8-level LDS tree; one more workgroup per set sums the partials.  ~8 tagged elements per
+    // lane: the kernel is a dependency chain (lane-local additions, then the two trees), so more lanes than that only lengthen the second tree.
+    if (nsets < 1 || nsets > MSM_MAX_SETS) { set_error("ones-sum: bad set count"); return ZKG_ERROR; }
+    const unsigned blocks = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (n1 + 2047) / 2048));
+    o.g2 = sizeof(F) != sizeof(Fq); o.nsets = nsets;
+    if (o.partials.reserve((size_t)nsets * (blocks + 1) * sizeof(XYZZ<F>))) return ZKG_ERROR;
+    if (!o.host) { if (!hip_ok(hipHostMalloc(&o.host, MSM_MAX_SETS * sizeof(G2), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return ZKG_ERROR; }
     XYZZ<F> *part = o.partials.as<XYZZ<F>>();
-    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks), dim3(256), 256 * sizeof(XYZZ<F>), s, d_bases, d_tags, n1, index_sub, part);
-    hipLaunchKernelGGL(k_sum_partials<F>, dim3(1), dim3(256), 256 * sizeof(XYZZ<F>), s, part, blocks, part + blocks);
+    ViewSet<F> views;
+    for (int i = 0; i < MSM_MAX_SETS; ++i) { const MsmBases &b = sets[i < nsets ? i : 0]; views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), 0, nullptr, b.index_sub, 1}; }
+    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(XYZZ<F>), s, views, d_tags, n1, part);
+    hipLaunchKernelGGL(k_sum_partials<F>, dim3((unsigned)nsets), dim3(256), 256 * sizeof(XYZZ<F>), s, part, blocks);
     if (hipGetLastError() != hipSuccess) { set_error("ones-sum launch failed"); return ZKG_ERROR; }
-    ZK_HIP(hipMemcpyAsync(o.host, part + blocks, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+    for (int i = 0; i < nsets; ++i)
+        ZK_HIP(hipMemcpyAsync((char *)o.host + (size_t)i * sizeof(XYZZ<F>), part + (size_t)i * (blocks + 1) + blocks, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
     return ZKG_OK;
 }
-int ones_sum_launch_g1(OnesSum &o, const G1Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) { return ones_sum_launch_t<Fq>(o, d_bases, d_tags, n1, index_sub, s); }
-int ones_sum_launch_g2(OnesSum &o, const G2Affine *d_bases, const uint8_t *d_tags, size_t n1, uint32_t index_sub, hipStream_t s) { return ones_sum_launch_t<Fq2>(o, d_bases, d_tags, n1, index_sub, s); }
+int ones_sum_launch(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *d_tags, size_t n1, hipStream_t s) {
+    for (int i = 1; i < nsets; ++i) if (sets[i].g2 != sets[0].g2) { set_error("ones-sum: one field per launch"); return ZKG_ERROR; }
+    return sets[0].g2 ? ones_sum_launch_t<Fq2>(o, sets, nsets, d_tags, n1, s) : ones_sum_launch_t<Fq>(o, sets, nsets, d_tags, n1, s);
+}
 void OnesSum::release() { partials.release(); if (host) (void)hipHostFree(host); host = nullptr; }
 
 // ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
@@ -954,6 +1031,7 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_fold<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_THREADS * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
@@ -966,7 +1044,7 @@ void msm_release_all() {
     MsmJob &j = g_default_job;
     std::lock_guard<std::mutex> lk(j.mu);
     for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted, &j.rx_tmp, &j.rx_meta}) b->release();
-    for (auto &sl : j.slot) sl.release();
+    for (auto &gr : j.group) gr.release();
 }
 
 }  // namespace zk

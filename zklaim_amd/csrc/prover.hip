@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,13 +39,36 @@ struct ProverSlot {
     hipStream_t stream = nullptr;               // upload + split + mat-vec + NTT stream
     // witness multi-exponentiations: one job for the three G1 queries (A, B_g1, L share the digit sort), one for B_g2; H on its own
     zk::MsmJob *job_w1 = nullptr, *job_w2 = nullptr, *job_h = nullptr;
-    zk::OnesSum ones_a, ones_b1, ones_l, ones_b2;
+    zk::OnesSum ones_g1, ones_g2;               // flat sums of the bases whose witness element is one: (A, B_g1, L) and B_g2, on streams of their own
+    hipStream_t stream_o = nullptr;
     hipEvent_t ev[20]; bool ev_ok = false, ready = false;
     float stage_ms[8] = {0};
     // the proof in flight between prove_enqueue and prove_finish
     uint32_t *flag_host = nullptr;              // pinned: [0] lands the satisfiability flag, [1] the count of non-bit witness elements
     bool check = false; zk::Fr r, s;
     std::chrono::steady_clock::time_point t0;
+};
+
+// Host-side fixed-base table of one key element P (alpha_1, beta_1, delta_1, delta_2): entry [j][d-1] = d * 16^j * P, affine.  k * P for a
+// 254-bit k is then 64 mixed additions and no doubling (~20 us for G1) instead of 254 doublings + ~127 additions (~130 us): the products
+// r*delta, s*delta, rs*delta, s*alpha, r*beta that every proof needs cost less than one variable-base multiplication together.
+template <class F> struct CombTable {
+    std::vector<zk::Affine<F>> t;               // 64 x 15
+    void build(const zk::Affine<F> &base) {
+        t.assign(64 * 15, zk::Affine<F>::inf());
+        zk::XYZZ<F> row = zk::XYZZ<F>::from_affine(base);                        // 16^j * P
+        for (int j = 0; j < 64; ++j) {
+            zk::XYZZ<F> cur = row;
+            zk::Affine<F> row_aff = row.to_affine();
+            for (int d = 1; d <= 15; ++d) { t[j * 15 + d - 1] = cur.to_affine(); cur.madd(row_aff); }
+            for (int k = 0; k < 4; ++k) row = row.dbl();
+        }
+    }
+    zk::XYZZ<F> mul(const uint32_t k[8]) const {                                  // canonical little-endian scalar
+        zk::XYZZ<F> acc = zk::XYZZ<F>::inf();
+        for (int j = 0; j < 64; ++j) { uint32_t d = (k[j >> 3] >> (4 * (j & 7))) & 15u; if (d) acc.madd(t[j * 15 + d - 1]); }
+        return acc;
+    }
 };
 
 struct zkg_crs {
@@ -54,6 +78,7 @@ struct zkg_crs {
     // reduction per multi-exponentiation and no doubling on the host (W x the key in HBM: 6 GB at 37 payloads, 2 % of the 288 GB)
     zk::WindowTable A_query, B_g1, B_g2, H_query, L_query;
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
+    CombTable<zk::Fq> alpha1_comb, beta1_comb, delta1_comb; CombTable<zk::Fq2> delta2_comb;
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
     zk::StepDomain *sdom = nullptr;             // ... or step_radix2_domain (m = 2^(log_m-1) + 2^b); exactly one is set
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
@@ -259,11 +284,22 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);             // numerically lower = higher priority
-        // Stream priorities as measured in round 1: the latency-bound witness multi-exponentiations high (their few wavefronts are placed
-        // at once), the wide mat-vec / NTT stream and H low (they fill what is left).
-        ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_lo), "hipStreamCreate", __FILE__, __LINE__);
-        S.job_w1 = msm_job_create(nullptr, true, true); S.job_w2 = msm_job_create(nullptr, true, true); S.job_h = msm_job_create(nullptr, true, false);
-        ok = ok && S.job_w1 && S.job_w2 && S.job_h;
+        // Four streams, so that each can have a hardware queue (a compute pipe) of its own — with more, two streams share a pipe and a
+        // small kernel waits until every workgroup of the other stream's big kernel has been dispatched (seen in the kernel trace: the G1
+        // witness job started 1.3 ms into a 1.9 ms proof):
+        //   stream    upload, split, mat-vec, 7 NTTs and the H multi-exponentiation (H needs the NTTs anyway): the critical path
+        //   job_w2    B_g2 over the non-bit witness elements (the longest latency chain)
+        //   job_w1    A, B_g1 and L over the same elements, batched
+        //   stream_o  the flat sums over the ones: B_g2, then A / B_g1 / L batched
+        // ZKG_PRIO (tuning aid): bit 0 = `stream` high priority, bit 1 = witness jobs high, bit 2 = ones-sums high.
+        static const char *pe = getenv("ZKG_PRIO");
+        const int pr = pe ? atoi(pe) : 1;
+        auto prio = [&](int bit) { return (pr >> bit) & 1 ? prio_hi : prio_lo; };
+        ok = hip_ok(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio(0)), "hipStreamCreate", __FILE__, __LINE__);
+        S.job_w1 = msm_job_create(nullptr, true, prio(1) == prio_hi); S.job_w2 = msm_job_create(nullptr, true, prio(1) == prio_hi);
+        S.job_h = ok ? msm_job_create(S.stream, false) : nullptr;
+        ok = ok && S.job_w1 && S.job_w2 && S.job_h &&
+             hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
             msm_job_set_window(S.job_w1, crs->A_query.c); msm_job_set_window(S.job_w2, crs->B_g2.c); msm_job_set_window(S.job_h, crs->H_query.c);
         }
@@ -280,9 +316,8 @@ static void slot_destroy(ProverSlot &S) {
     for (DevBuf *b : {&S.z, &S.aABC, &S.flag, &S.ntt_scratch, &S.up_tags, &S.up_idx, &S.up_vals, &S.wtags, &S.wlisted, &S.wcount}) b->release();
     msm_job_destroy(S.job_w1); msm_job_destroy(S.job_w2); msm_job_destroy(S.job_h);
     S.job_w1 = S.job_w2 = S.job_h = nullptr;
-    for (OnesSum *o : {&S.ones_a, &S.ones_b1, &S.ones_l, &S.ones_b2}) o->release();
-    if (S.stream) (void)hipStreamDestroy(S.stream);
-    S.stream = nullptr;
+    for (OnesSum *o : {&S.ones_g1, &S.ones_g2}) o->release();
+    for (hipStream_t *st : {&S.stream, &S.stream_o}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
     if (S.ev_ok) for (auto &e : S.ev) (void)hipEventDestroy(e);
     S.ev_ok = false;
     if (S.flag_host) (void)hipHostFree(S.flag_host);
@@ -338,6 +373,10 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     if (ok) {
         memcpy(&crs->alpha_g1, pk->alpha_g1, 64); memcpy(&crs->beta_g1, pk->beta_g1, 64); memcpy(&crs->delta_g1, pk->delta_g1, 64);
         memcpy(&crs->beta_g2, pk->beta_g2, 128); memcpy(&crs->delta_g2, pk->delta_g2, 128);
+        host_parallel_for(4, [&](int i) {
+            if (i == 0) crs->delta2_comb.build(crs->delta_g2); else if (i == 1) crs->delta1_comb.build(crs->delta_g1);
+            else if (i == 2) crs->alpha1_comb.build(crs->alpha_g1); else crs->beta1_comb.build(crs->beta_g1);
+        });
         if (shape.step) crs->sdom = step_domain(shape.m, nullptr); else crs->dom = ntt_domain(pk->log_m, nullptr);
         ok = crs->dom != nullptr || crs->sdom != nullptr;
     }
@@ -393,8 +432,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     const size_t n = crs->n, l = crs->l, m = crs->m;
     // H: uniformly random scalars, needs the NTT pipeline (event 2)
     {
-        hipStream_t js = msm_job_stream(S.job_h);
-        ZK_HIP(hipStreamWaitEvent(js, S.ev[2], 0));
+        hipStream_t js = msm_job_stream(S.job_h);                              // == S.stream: H follows the transforms in stream order
         (void)hipEventRecord(S.ev[8], js);
         const MsmBases h = table_set(crs->H_query, 0);
         if (msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true)) return ZKG_ERROR;
@@ -409,27 +447,26 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
     lap(S, "witness split read back");
     const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
+    const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))}, b2 = table_set(crs->B_g2, 0);
     {
-        hipStream_t js = msm_job_stream(S.job_w2);                             // G2 first: the longest chain
+        hipStream_t js = msm_job_stream(S.job_w2);                             // G2 first: the longest chains
+        ZK_HIP(hipStreamWaitEvent(S.stream_o, S.ev[0], 0));
+        if (ones_sum_launch(S.ones_g2, &b2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+        (void)hipEventRecord(S.ev[10], S.stream_o);                            // the G2 sum has landed (the G1 sums follow on the same stream)
         ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
         (void)hipEventRecord(S.ev[6], js);
-        if (ones_sum_launch_g2(S.ones_b2, crs->B_g2.buf.as<G2Affine>(), tags, n + 1, 0, js)) return ZKG_ERROR;
-        const MsmBases b2 = table_set(crs->B_g2, 0);
         if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
         (void)hipEventRecord(S.ev[7], js);
-        if (g_serial_msm) (void)hipStreamSynchronize(js);
+        if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
     }
     {
         hipStream_t js = msm_job_stream(S.job_w1);
+        if (ones_sum_launch(S.ones_g1, g1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
         ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
         (void)hipEventRecord(S.ev[4], js);
-        if (ones_sum_launch_g1(S.ones_a, crs->A_query.buf.as<G1Affine>(), tags, n + 1, 0, js) ||
-            ones_sum_launch_g1(S.ones_b1, crs->B_g1.buf.as<G1Affine>(), tags, n + 1, 0, js) ||
-            ones_sum_launch_g1(S.ones_l, crs->L_query.buf.as<G1Affine>(), tags, n + 1, (uint32_t)(l + 1), js)) return ZKG_ERROR;
-        const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))};
         if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
         (void)hipEventRecord(S.ev[5], js);
-        if (g_serial_msm) (void)hipStreamSynchronize(js);
+        if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
     }
     lap(S, "msm jobs enqueued");
     return ZKG_OK;
@@ -437,18 +474,21 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
 static void slot_drain(const zkg_crs *, ProverSlot &S) {                      // after an error: nothing of this slot may still be running
     (void)hipStreamSynchronize(S.stream);
     for (MsmJob *j : {S.job_w1, S.job_w2, S.job_h}) if (j) (void)hipStreamSynchronize(msm_job_stream(j));
+    if (S.stream_o) (void)hipStreamSynchronize(S.stream_o);
 }
 static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t *proof_len) {
     hipStream_t s = S.stream;
     G1 W1[3]; G2 Bt2; G1 Ht;
-    // host work that needs only the CRS and (r, s): overlaps the GPU
+    // host work that needs only the key and (r, s), from the fixed-base tables: overlaps the GPU.
+    //   A = alpha + W_a + r delta,  B = beta + W_b + s delta (in G2, and its copy B_1 in G1),
+    //   C = H + L + s A + r B_1 - rs delta = H + L + (s alpha + r beta_1 + rs delta) + s W_a + r W_b
+    // (W_a, W_b, L, H: the four multi-exponentiations).  The same group elements as libsnark's expression order gives; bytes identical.
     uint32_t rc[8], sc[8], rsc[8];
     canonical_limbs(S.r, rc); canonical_limbs(S.s, sc); canonical_limbs(S.r * S.s, rsc);
-    G1 alpha = G1::from_affine(crs->alpha_g1), beta1 = G1::from_affine(crs->beta_g1), delta1 = G1::from_affine(crs->delta_g1);
-    G2 beta2 = G2::from_affine(crs->beta_g2), delta2 = G2::from_affine(crs->delta_g2);
-    G1 r_delta1 = delta1.mul(rc, 8), s_delta1 = delta1.mul(sc, 8), rs_delta1 = delta1.mul(rsc, 8);
-    G2 s_delta2 = delta2.mul(sc, 8);
-    lap(S, "crs-only host products");
+    G1 gA = G1::from_affine(crs->alpha_g1); gA.add(crs->delta1_comb.mul(rc));                          // alpha + r delta
+    G1 c_fixed = crs->alpha1_comb.mul(sc); c_fixed.add(crs->beta1_comb.mul(rc)); c_fixed.add(crs->delta1_comb.mul(rsc));   // s alpha + r beta_1 + rs delta
+    G2 gB2 = G2::from_affine(crs->beta_g2); gB2.add(crs->delta2_comb.mul(sc));                         // beta + s delta
+    lap(S, "key-only host products");
     if (S.check) {
         ZK_HIP(hipEventSynchronize(S.ev[3]));
         if (S.flag_host[0]) {                                                // drain the speculative MSMs, then refuse like snark.cpp:121-124
@@ -456,21 +496,22 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
             set_error("constraint system not satisfied; not creating proof"); return ZKG_UNSATISFIED;
         }
     }
-    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing: the
-    //      witness queries end early, so s*A + r*B_1 - rs*delta (two 254-bit scalar multiplications) is formed while H is still running
-    if (msm_job_finish(S.job_w1, W1, nullptr)) { slot_drain(crs, S); return ZKG_ERROR; }
-    W1[0].add(*reinterpret_cast<const G1 *>(S.ones_a.host)); W1[1].add(*reinterpret_cast<const G1 *>(S.ones_b1.host)); W1[2].add(*reinterpret_cast<const G1 *>(S.ones_l.host));
-    G1 gA = alpha; gA.add(W1[0]); gA.add(r_delta1);                         // A = alpha + sum a_i A_i(t) + r delta
-    G1 gB1 = beta1; gB1.add(W1[1]); gB1.add(s_delta1);                      // B = beta + sum a_i B_i(t) + s delta   (G1 copy)
-    G1 gC = gA.mul(sc, 8); gC.add(gB1.mul(rc, 8)); gC.add(rs_delta1.neg());
-    gC.add(W1[2]);
-    lap(S, "s*A + r*B1 - rs*delta + L");
-    if (msm_job_finish(S.job_w2, nullptr, &Bt2)) { slot_drain(crs, S); return ZKG_ERROR; }
-    Bt2.add(*reinterpret_cast<const G2 *>(S.ones_b2.host));
-    G2 gB2 = beta2; gB2.add(Bt2); gB2.add(s_delta2);                        //                                        (G2)
+    // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing
+    if (msm_job_finish(S.job_w1, W1, nullptr) || !hip_ok(hipStreamSynchronize(S.stream_o), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
+    for (int i = 0; i < 3; ++i) W1[i].add(S.ones_g1.g1(i));                   // bucket method over the non-bit elements + flat sum over the ones
+    // the two variable-base products s W_a and r W_b: the second one on a helper thread
+    auto rWb = std::async(std::launch::async, [&] { return W1[1].mul(rc, 8); });
+    G1 gC = W1[0].mul(sc, 8);
+    gA.add(W1[0]);
     size_t off = 0;
-    off += ser_g1(proof_out + off, gA); off += ser_g2(proof_out + off, gB2);
-    lap(S, "A, B serialised");
+    off += ser_g1(proof_out + off, gA);
+    gC.add(rWb.get()); gC.add(c_fixed); gC.add(W1[2]);
+    lap(S, "A serialised, s*Wa + r*Wb + L");
+    if (msm_job_finish(S.job_w2, nullptr, &Bt2) || !hip_ok(hipEventSynchronize(S.ev[10]), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
+    Bt2.add(S.ones_g2.g2pt(0));
+    gB2.add(Bt2);
+    off += ser_g2(proof_out + off, gB2);
+    lap(S, "B serialised");
     if (msm_job_finish(S.job_h, &Ht, nullptr)) { slot_drain(crs, S); return ZKG_ERROR; }
     gC.add(Ht);                                                             // C = H_t + L_t + s A + r B_1 - rs delta
     off += ser_g1(proof_out + off, gC);
