@@ -35,6 +35,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 namespace zk {
@@ -992,39 +993,98 @@ int ones_sum_launch(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *
 }
 void OnesSum::release() { partials.release(); if (host) (void)hipHostFree(host); host = nullptr; }
 
-// ---- fixed-base batch: out[i] = k_i * base, table of 2^j * base (j < 254) ----------------------
+// ---- fixed-base batch: out[i] = k_i * base (libff batch_exp with a window table; libsnark's generator, snark.cpp:91) --------------
+//      Table: entry [j][d-1] = d * 256^j * base (j < 32, d = 1..255), affine, 522 KB for G1: a scalar is 32 byte digits, i.e. at most
+//      32 mixed additions and no doubling (the first build added bit by bit: 254 conditional additions).  A lane takes FB_K scalars and
+//      keeps their results in registers, so that ONE field inversion (Montgomery's trick over ZZZ) normalises all of them: the kernel
+//      writes each affine point once and nothing else (the first build's out-of-line to_affine spilt to scratch: 123x the output bytes).
+static constexpr int FB_WINDOWS = 32, FB_DIGITS = 255, FB_K = 4;
+template <class F>
+__global__ __launch_bounds__(256) void k_fixed_table(const Affine<F> *rows /* 256^j * base */, Affine<F> *table) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FB_WINDOWS * FB_DIGITS) return;
+    const uint32_t j = t / FB_DIGITS, d = t % FB_DIGITS + 1;
+    const Affine<F> r = rows[j];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 7; bit >= 0; --bit) { acc = acc.dbl(); if ((d >> bit) & 1u) acc.madd(r); }
+    XYZZ<F> fin = acc;
+    table[t] = fin.to_affine().normalized();
+}
 template <class F>
 __global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, const uint32_t *scalars, size_t n, int mont, Affine<F> *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr f;
-    for (int j = 0; j < 8; ++j) f.v[j] = scalars[8 * i + j];
-    if (mont) f = f.from_mont();                                                // the generator hands over Montgomery Fr; the ABI canonical limbs
-    else f = f.normalized();
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int b = 0; b < 254; ++b)
-        if ((f.v[b >> 5] >> (b & 31)) & 1u) acc.madd(table[b]);
-    XYZZ<F> fin = acc;                     // to_affine() is out of line: only this copy has its address taken, the loop's accumulator stays in registers
-    out[i] = fin.to_affine().normalized();
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = lane * FB_K;
+    if (i0 >= n) return;
+    F x[FB_K], y[FB_K], zz[FB_K], zzz[FB_K];
+#pragma unroll
+    for (int k = 0; k < FB_K; ++k) {
+        XYZZ<F> acc = XYZZ<F>::inf();
+        if (i0 + k < n) {
+            Fr f;
+            for (int j = 0; j < 8; ++j) f.v[j] = scalars[8 * (i0 + k) + j];
+            if (mont) f = f.from_mont();                                        // the generator hands over Montgomery Fr; the ABI canonical limbs
+            else f = f.normalized();
+            for (int j = 0; j < FB_WINDOWS; ++j) {
+                const uint32_t d = (f.v[j >> 2] >> (8 * (j & 3))) & 255u;
+                if (d) acc.madd(table[j * FB_DIGITS + d - 1]);
+            }
+        }
+        x[k] = acc.x; y[k] = acc.y; zz[k] = acc.zz; zzz[k] = acc.zzz;
+    }
+    // Montgomery's trick over the FB_K values of ZZZ (infinity: ZZZ = 0, replaced by one and restored below)
+    F pre[FB_K], run = F::one();
+#pragma unroll
+    for (int k = 0; k < FB_K; ++k) { pre[k] = run; if (!zzz[k].is_zero()) run = run * zzz[k]; }
+    F inv = run.inverse();
+#pragma unroll
+    for (int k = FB_K - 1; k >= 0; --k) {
+        if (i0 + k >= n) continue;
+        if (zzz[k].is_zero()) { out[i0 + k] = Affine<F>::inf(); continue; }
+        F zi = inv * pre[k];                                                    // 1 / ZZZ_k
+        inv = inv * zzz[k];
+        F t = zi * zz[k];                                                       // ZZ / ZZZ = 1 / Z
+        F zi2 = t.sqr();                                                        // 1 / ZZ
+        out[i0 + k] = Affine<F>{x[k] * zi2, y[k] * zi}.normalized();
+    }
 }
 
+// table per base point, built once per process (the generator always uses the curve's generators)
+template <class F> struct FixedTableCache { std::mutex mu; std::vector<std::pair<Affine<F>, DevBuf>> entries; };
+template <class F> static FixedTableCache<F> &fixed_cache() { static FixedTableCache<F> c; return c; }
+template <class F>
+static const Affine<F> *fixed_table_for(const Affine<F> &base, hipStream_t s) {
+    FixedTableCache<F> &c = fixed_cache<F>();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (auto &e : c.entries) if (memcmp(&e.first, &base, sizeof(base)) == 0) return e.second.template as<Affine<F>>();
+    std::vector<Affine<F>> rows(FB_WINDOWS);
+    XYZZ<F> cur = XYZZ<F>::from_affine(base);
+    for (int j = 0; j < FB_WINDOWS; ++j) { rows[j] = cur.to_affine(); for (int k = 0; k < 8; ++k) cur = cur.dbl(); }
+    DevBuf d_rows, d_table;
+    if (d_rows.reserve(rows.size() * sizeof(Affine<F>)) || d_table.reserve((size_t)FB_WINDOWS * FB_DIGITS * sizeof(Affine<F>))) return nullptr;
+    if (!hip_ok(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(Affine<F>), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__)) return nullptr;
+    hipLaunchKernelGGL(k_fixed_table<F>, dim3((FB_WINDOWS * FB_DIGITS + 255) / 256), dim3(256), 0, s, d_rows.as<Affine<F>>(), d_table.as<Affine<F>>());
+    const bool ok = hipGetLastError() == hipSuccess && hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);
+    d_rows.release();
+    if (!ok) { d_table.release(); set_error("fixed-base table build failed"); return nullptr; }
+    c.entries.emplace_back(base, d_table);
+    return c.entries.back().second.template as<Affine<F>>();
+}
 template <class F>
 static int fixed_base(const Affine<F> &base, const uint32_t *d_scalars, size_t n, Affine<F> *d_out, hipStream_t s, bool mont) {
-    std::vector<Affine<F>> table(254);
-    XYZZ<F> cur = XYZZ<F>::from_affine(base);
-    for (int b = 0; b < 254; ++b) { table[b] = cur.to_affine(); cur = cur.dbl(); }
-    DevBuf d_table;
-    if (d_table.reserve(table.size() * sizeof(Affine<F>))) return ZKG_ERROR;
-    ZK_HIP(hipMemcpyAsync(d_table.p, table.data(), table.size() * sizeof(Affine<F>), hipMemcpyHostToDevice, s));
-    if (n) hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_table.as<Affine<F>>(), d_scalars, n, (int)mont, d_out);
+    const Affine<F> *table = fixed_table_for<F>(base, s);
+    if (!table) return ZKG_ERROR;
+    const size_t lanes = (n + FB_K - 1) / FB_K;
+    if (n) hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, table, d_scalars, n, (int)mont, d_out);
     hipError_t e = hipGetLastError();
     ZK_HIP(hipStreamSynchronize(s));
-    d_table.release();
     if (e != hipSuccess) { set_error("fixed_base launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
 int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1Affine *d_out, hipStream_t s, bool mont) { return fixed_base<Fq>(base, d_scalars, n, d_out, s, mont); }
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s, bool mont) { return fixed_base<Fq2>(base, d_scalars, n, d_out, s, mont); }
+static void fixed_tables_release() {
+    { auto &c = fixed_cache<Fq>(); std::lock_guard<std::mutex> lk(c.mu); for (auto &e : c.entries) e.second.release(); c.entries.clear(); }
+    { auto &c = fixed_cache<Fq2>(); std::lock_guard<std::mutex> lk(c.mu); for (auto &e : c.entries) e.second.release(); c.entries.clear(); }
+}
 
 int msm_configure() {
     bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
@@ -1041,6 +1101,7 @@ int msm_configure() {
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 void msm_release_all() {
+    fixed_tables_release();
     MsmJob &j = g_default_job;
     std::lock_guard<std::mutex> lk(j.mu);
     for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted, &j.rx_tmp, &j.rx_meta}) b->release();

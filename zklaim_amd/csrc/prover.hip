@@ -209,7 +209,8 @@ struct WitnessSrc {                           // dense: n x 4 limbs; or sparse: 
     const uint64_t *dense = nullptr;
     const uint8_t *tags = nullptr; const uint32_t *idx = nullptr; const uint64_t *vals = nullptr; size_t count = 0;
 };
-static int compute_h(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want_flag) {
+// phase 1 of r1cs_to_qap_witness_map: z = [1 | w] resident and split, the three mat-vecs, the satisfiability flag
+static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want_flag) {
     hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
     Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -247,6 +248,14 @@ static int compute_h(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want
         if (S.ev_ok) (void)hipEventRecord(S.ev[3], s);
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[1], s);
+    if (hipGetLastError() != hipSuccess) { set_error("prover kernel launch failed"); return ZKG_ERROR; }
+    return ZKG_OK;
+}
+// phase 2: the seven transforms and the pointwise step -> coefficients_for_H in aA
+static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
+    hipStream_t s = S.stream;
+    const size_t m = crs->m;
+    Fr *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
     Fr *scr = S.ntt_scratch.as<Fr>();
     const unsigned grid_m = (unsigned)((m + 255) / 256);
     if (crs->dom) {
@@ -408,7 +417,7 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
     std::lock_guard<std::mutex> lk(crs->mu);
     ProverSlot &S = crs->slot[0];
     WitnessSrc W; W.dense = witness;
-    if (compute_h(crs, S, W, false)) return ZKG_ERROR;
+    if (compute_h_matvec(crs, S, W, false) || compute_h_transforms(crs, S)) return ZKG_ERROR;
     ZK_HIP(hipStreamSynchronize(S.stream));
     ZK_HIP(hipMemcpy(h_out, S.aABC.p, crs->m * 32, hipMemcpyDeviceToHost));
     memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
@@ -427,49 +436,54 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     S.t0 = std::chrono::steady_clock::now();
     S.check = check; memcpy(S.r.v, r_, 32); memcpy(S.s.v, s_, 32);
     S.flag_host[0] = 0; S.flag_host[1] = 0;
-    if (compute_h(crs, S, witness, check)) return ZKG_ERROR;
-    lap(S, "h pipeline enqueued");
+    if (compute_h_matvec(crs, S, witness, check)) return ZKG_ERROR;
+    lap(S, "upload + mat-vec enqueued");
     const size_t n = crs->n, l = crs->l, m = crs->m;
-    // H: uniformly random scalars, needs the NTT pipeline (event 2)
-    {
-        hipStream_t js = msm_job_stream(S.job_h);                              // == S.stream: H follows the transforms in stream order
+    // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — ~3 % of a credential's
+    // witness — through the bucket method as a gathered subset.  The count of "the rest" sizes the launches, so a helper thread waits
+    // for the split (event 0), reads it and queues the four witness streams' work while this thread queues the critical path.
+    auto witness_jobs = std::async(std::launch::async, [&]() -> int {
+        ZK_HIP(hipEventSynchronize(S.ev[0]));
+        const size_t listed = S.flag_host[1];
+        if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
+        const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
+        const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))}, b2 = table_set(crs->B_g2, 0);
+        {
+            hipStream_t js = msm_job_stream(S.job_w2);                         // G2 first: the longest chains
+            ZK_HIP(hipStreamWaitEvent(S.stream_o, S.ev[0], 0));
+            if (ones_sum_launch(S.ones_g2, &b2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            (void)hipEventRecord(S.ev[10], S.stream_o);                        // the G2 sum has landed (the G1 sums follow on the same stream)
+            ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+            (void)hipEventRecord(S.ev[6], js);
+            if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
+            (void)hipEventRecord(S.ev[7], js);
+            if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
+        }
+        {
+            hipStream_t js = msm_job_stream(S.job_w1);
+            if (ones_sum_launch(S.ones_g1, g1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+            (void)hipEventRecord(S.ev[4], js);
+            if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
+            (void)hipEventRecord(S.ev[5], js);
+            if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
+        }
+        return ZKG_OK;
+    });
+    int rc = compute_h_transforms(crs, S);
+    lap(S, "transforms enqueued");
+    // H: uniformly random scalars, follows the transforms in stream order
+    if (rc == ZKG_OK) {
+        hipStream_t js = msm_job_stream(S.job_h);                              // == S.stream
         (void)hipEventRecord(S.ev[8], js);
         const MsmBases h = table_set(crs->H_query, 0);
-        if (msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true)) return ZKG_ERROR;
+        rc = msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true);
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
-    // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — ~3 % of a credential's
-    // witness — through the bucket method as a gathered subset.  The count of "the rest" sizes the launch, so the host reads it back
-    // here, after everything that does not depend on it is queued.
-    ZK_HIP(hipEventSynchronize(S.ev[0]));
-    const size_t listed = S.flag_host[1];
-    if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
-    lap(S, "witness split read back");
-    const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
-    const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))}, b2 = table_set(crs->B_g2, 0);
-    {
-        hipStream_t js = msm_job_stream(S.job_w2);                             // G2 first: the longest chains
-        ZK_HIP(hipStreamWaitEvent(S.stream_o, S.ev[0], 0));
-        if (ones_sum_launch(S.ones_g2, &b2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
-        (void)hipEventRecord(S.ev[10], S.stream_o);                            // the G2 sum has landed (the G1 sums follow on the same stream)
-        ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
-        (void)hipEventRecord(S.ev[6], js);
-        if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
-        (void)hipEventRecord(S.ev[7], js);
-        if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
-    }
-    {
-        hipStream_t js = msm_job_stream(S.job_w1);
-        if (ones_sum_launch(S.ones_g1, g1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
-        ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
-        (void)hipEventRecord(S.ev[4], js);
-        if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
-        (void)hipEventRecord(S.ev[5], js);
-        if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
-    }
+    const int rc_w = witness_jobs.get();
     lap(S, "msm jobs enqueued");
-    return ZKG_OK;
+    return rc == ZKG_OK ? rc_w : rc;
 }
 static void slot_drain(const zkg_crs *, ProverSlot &S) {                      // after an error: nothing of this slot may still be running
     (void)hipStreamSynchronize(S.stream);
