@@ -144,6 +144,22 @@ int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n,
 int zkg_g1_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[12]);
 int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]);
 
+/* ---- several GPUs in ONE process: the G1 multi-exponentiation sharded by points.
+ *      zkg_init_multi: zkg_init(devices[0]) plus the per-device kernel setup of the other devices.  A device may be listed more
+ *      than once (two shards on one GPU: how a single-GPU box rehearses the path).
+ *      zkg_msm_g1_shards_upload: splits n affine bases (HOST pointer) into ndev contiguous shards, shard i resident on devices[i]
+ *      with its own stream and workspace.
+ *      zkg_msm_g1_multi: scalars n x 4 canonical limbs (HOST pointer).  One host thread per shard uploads that shard's scalar
+ *      slice and runs the complete single-GPU Pippenger; the ndev partial points are added on the host (RCCL has no elliptic-curve
+ *      reduction; the exchange is 96 bytes per GPU).  partials_jac (optional, ndev x 12 limbs) receives the per-shard results.
+ *      Result == zkg_msm_g1 on the same inputs, bit for bit.                                                                  */
+typedef struct zkg_msm_shards zkg_msm_shards;
+int zkg_init_multi(const int *devices, int ndev);
+zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const int *devices, int ndev);
+void zkg_msm_g1_shards_free(zkg_msm_shards *shards);
+size_t zkg_msm_g1_shards_count(const zkg_msm_shards *shards, size_t *points);
+int zkg_msm_g1_multi(const zkg_msm_shards *shards, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac);
+
 /* ---- fixed-base batch: out[i] = scalars[i] * base (affine out).  The batch_exp of
  *      libsnark's generator (snark.cpp:91); used here to build synthetic bases on device. */
 int zkg_g1_fixed_base_dev(const uint64_t base[8], const void *d_scalars, size_t n, void *d_out_affine, void *stream);

@@ -187,3 +187,26 @@ def _mostly_bits_case(zkg, oracle, n):
         a = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n)
         b = zkg.msm_g1_dev(d_b.data_ptr(), d_sc.data_ptr(), n, mostly_bits=True)
         assert np.array_equal(a, b) and np.array_equal(a, oracle.msm_g1(bases, sc, oracle.MIXED))
+
+
+@pytest.mark.parametrize("n,devices", [(10007, [0, 0, 0]), (2, [0, 0, 0]), (40000, [0, 0]), (0, [0, 0])])
+def test_multi_device_shards_in_one_process(zkg, oracle, n, devices):
+    """zkg_msm_g1_multi (the C-ABI multi-GPU entry point: bases sharded by points, one host thread per shard, partials added on the
+    host).  A single-GPU box rehearses it with one device listed several times: same threads, streams and workspaces, same result as
+    the single-GPU call and the oracle; shards of unequal and of zero size included."""
+    zkg.init_multi(devices)
+    _, bases, _ = dev_bases_g1(zkg, max(n, 1), 4000 + n)
+    bases = bases[:n]
+    sc = random_fr_canonical(max(n, 1), 4001 + n)[:n]
+    sh = zkg.MsmShards(bases, devices)
+    got, parts = sh.msm(sc, with_partials=True)
+    exp = oracle.msm_g1(bases, sc) if n else g1_jac_expected(None)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got, zkg.msm_g1(bases, sc))
+    assert np.array_equal(zkg.g1_sum(parts), got)                       # the exchange step: ndev normalised partials, summed
+    bounds = [n * i // len(devices) for i in range(len(devices) + 1)]
+    for i in range(len(devices)):
+        lo, hi = bounds[i], bounds[i + 1]
+        assert np.array_equal(parts[i], oracle.msm_g1(bases[lo:hi], sc[lo:hi]) if hi > lo else g1_jac_expected(None))
+    assert np.array_equal(sh.msm(sc), got)                              # workspaces are reused across calls
+    sh.free()

@@ -20,7 +20,8 @@ DECLARED_SYMBOLS = [
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
-    "zkg_compat_reset", "zkg_field_op",
+    "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
+    "zkg_msm_g1_multi",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -156,6 +157,46 @@ def msm_g2(bases, scalars):
     bases = _u64(bases); scalars = _u64(scalars); out = np.zeros(24, np.uint64)
     _check(lib().zkg_msm_g2(_p(bases), _p(scalars), C.c_size_t(scalars.size // 4), _p(out)), "zkg_msm_g2")
     return out
+
+
+def init_multi(devices):
+    global _initialised
+    d = (C.c_int * len(devices))(*devices)
+    _check(lib().zkg_init_multi(d, len(devices)), "zkg_init_multi")
+    _initialised = True
+
+
+class MsmShards:
+    """G1 bases sharded by points over several devices of this process (zkg_msm_g1_shards_upload); msm() = zkg_msm_g1_multi"""
+
+    def __init__(self, bases, devices):
+        bases = _u64(bases)
+        L = lib()
+        L.zkg_msm_g1_shards_upload.restype = C.c_void_p
+        L.zkg_msm_g1_shards_upload.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.zkg_msm_g1_shards_free.argtypes = [C.c_void_p]
+        L.zkg_msm_g1_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        d = (C.c_int * len(devices))(*devices)
+        self.n = bases.size // 8; self.ndev = len(devices)
+        self._h = L.zkg_msm_g1_shards_upload(_p(bases), self.n, d, len(devices))
+        if not self._h:
+            raise ZkgError("zkg_msm_g1_shards_upload failed: " + L.zkg_last_error().decode())
+
+    def msm(self, scalars, with_partials=False):
+        scalars = _u64(scalars); out = np.zeros(12, np.uint64); parts = np.zeros((self.ndev, 12), np.uint64)
+        assert scalars.size // 4 == self.n
+        _check(lib().zkg_msm_g1_multi(C.c_void_p(self._h), _p(scalars), _p(out), _p(parts)), "zkg_msm_g1_multi")
+        return (out, parts) if with_partials else out
+
+    def free(self):
+        if self._h:
+            lib().zkg_msm_g1_shards_free(C.c_void_p(self._h)); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 SCALARS_MONT, SCALARS_MOSTLY_BITS = 1, 2

@@ -346,6 +346,87 @@ int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t
     return field_op_run<Fq2>(op, a, binary ? b : nullptr, n, out);
 }
 
+// ---- one process, several GPUs: the G1 multi-exponentiation sharded by points.  Every shard is a resident slice of
+//      the bases on one device with its own stream and workspace; a call hands each shard its slice of the scalars on a host thread of
+//      its own (hipSetDevice is per thread), the shards run the complete single-GPU Pippenger concurrently, and the partial points — 96
+//      bytes each — are added on the host.  There is no data-path collective: RCCL has no elliptic-curve reduction, and a sum of
+//      ndev points is not worth a kernel.  (The one-process-per-GPU form of the same exchange is zklaim_amd/dist.py over RCCL.)
+struct zkg_msm_shards {
+    struct Shard { int device = 0; size_t first = 0, n = 0; DevBuf bases, scalars; MsmJob *job = nullptr; };
+    std::vector<Shard> shards; size_t n = 0;
+};
+
+int zkg_init_multi(const int *devices, int ndev) {
+    if (!devices || ndev < 1) { set_error("zkg_init_multi: bad argument"); return ZKG_ERROR; }
+    if (zkg_init(devices[0])) return ZKG_ERROR;                                   // also the calling thread's device for the single-GPU entry points
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    int count = 0;
+    (void)hipGetDeviceCount(&count);
+    for (int i = 1; i < ndev; ++i) {
+        if (devices[i] < 0 || devices[i] >= count) { set_error("zkg_init_multi: bad device index"); return ZKG_ERROR; }
+        ZK_HIP(hipSetDevice(devices[i]));
+        kernels_configure();                                                      // kernel attributes are per device
+    }
+    ZK_HIP(hipSetDevice(devices[0]));
+    return ZKG_OK;
+}
+
+zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const int *devices, int ndev) {
+    if (g_device < 0) { set_error("zkg_init not called"); return nullptr; }
+    if ((n && !bases) || !devices || ndev < 1 || ndev > 64) { set_error("zkg_msm_g1_shards_upload: bad argument"); return nullptr; }
+    zkg_msm_shards *h = new zkg_msm_shards();
+    h->n = n; h->shards.resize((size_t)ndev);
+    std::vector<int> rc((size_t)ndev, ZKG_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < ndev; ++i) {
+        zkg_msm_shards::Shard &sh = h->shards[(size_t)i];
+        sh.device = devices[i]; sh.first = n * (size_t)i / (size_t)ndev; sh.n = n * (size_t)(i + 1) / (size_t)ndev - sh.first;
+        th.emplace_back([&sh, &rc, i, bases] {
+            if (hipSetDevice(sh.device) != hipSuccess) { set_error("zkg_msm_g1_shards_upload: hipSetDevice failed"); rc[(size_t)i] = ZKG_ERROR; return; }
+            sh.job = msm_job_create(nullptr, true);
+            if (!sh.job || sh.bases.reserve(sh.n * 64 + 16) || sh.scalars.reserve(sh.n * 32 + 16) ||
+                (sh.n && !hip_ok(hipMemcpy(sh.bases.p, bases + 8 * sh.first, sh.n * 64, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__))) rc[(size_t)i] = ZKG_ERROR;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r : rc) if (r) { zkg_msm_g1_shards_free(h); return nullptr; }
+    return h;
+}
+void zkg_msm_g1_shards_free(zkg_msm_shards *h) {
+    if (!h) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (auto &sh : h->shards) { (void)hipSetDevice(sh.device); msm_job_destroy(sh.job); sh.bases.release(); sh.scalars.release(); }
+    (void)hipSetDevice(cur);
+    delete h;
+}
+size_t zkg_msm_g1_shards_count(const zkg_msm_shards *h, size_t *points) { if (points) *points = h ? h->n : 0; return h ? h->shards.size() : 0; }
+
+int zkg_msm_g1_multi(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
+    zkg_msm_shards *h = const_cast<zkg_msm_shards *>(h_);
+    if (!h || !out_jac || (h->n && !scalars)) { set_error("zkg_msm_g1_multi: bad argument"); return ZKG_ERROR; }
+    const size_t ns = h->shards.size();
+    std::vector<G1> part(ns, G1::inf()); std::vector<int> rc(ns, ZKG_OK);
+    auto run = [&](size_t i) {
+        zkg_msm_shards::Shard &sh = h->shards[i];
+        if (hipSetDevice(sh.device) != hipSuccess) { set_error("zkg_msm_g1_multi: hipSetDevice failed"); rc[i] = ZKG_ERROR; return; }
+        hipStream_t st = msm_job_stream(sh.job);
+        MsmBases set; set.p = sh.bases.p;
+        if ((sh.n && !hip_ok(hipMemcpyAsync(sh.scalars.p, scalars + 4 * sh.first, sh.n * 32, hipMemcpyHostToDevice, st), "H2D", __FILE__, __LINE__)) ||
+            msm_job_launch(sh.job, &set, 1, sh.scalars.as<uint32_t>(), sh.n, false) || msm_job_finish(sh.job, &part[i], nullptr)) rc[i] = ZKG_ERROR;
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < ns; ++i) th.emplace_back(run, i);
+    int cur = 0; (void)hipGetDevice(&cur);
+    run(0);                                                                       // shard 0 on the calling thread
+    (void)hipSetDevice(cur);
+    for (auto &t : th) t.join();
+    for (int r : rc) if (r) return ZKG_ERROR;
+    G1 acc = G1::inf();
+    for (size_t i = 0; i < ns; ++i) { if (partials_jac) store_norm(partials_jac + 12 * i, part[i]); acc.add(part[i]); }
+    store_norm(out_jac, acc);
+    return ZKG_OK;
+}
+
 void zkg_timing_reset(void) { g_dominant_timer.reset(); }
 float zkg_timing_dominant_ms(int *launches) { return g_dominant_timer.drain(launches); }
 
