@@ -71,6 +71,43 @@ G2_GEN_MONT = np.array([0x8e83b5d102bc2026, 0xdceb1935497b0172, 0xfbb8264797811a
                         0x64095b56c71856ee, 0xdc57f922327d3cbb, 0x55f935be33351076, 0x0da4a0e693fd6482], dtype=np.uint64)
 
 
+def msm_leg(zkg, torch, dist, logn, seed_off, steps, use_dist, world):
+    """one more resident-input G1 MSM leg at 2^logn points per rank (BASELINE configs[4]: 2^23 per GPU = 2^26 over 8): per-step wall time,
+    max over ranks, barrier + synchronize on both sides like the headline loop"""
+    from zklaim_amd import dist as zdist
+    n = 1 << logn
+    ks = splitmix_fr(n, SEED + 0x600 + seed_off); sc = splitmix_fr(n, SEED + 0x700 + seed_off)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    d_bases = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), n, d_bases.data_ptr())
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    del d_k
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)
+        return zdist.combine_partials_g1(part, device="cuda") if use_dist else part
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    step(); step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    per = dt / steps
+    return {"points_per_gpu": n, "total_points": n * world, "n_gpus": world, "steps": steps, "ms_per_step": round(per * 1e3, 3),
+            "GBps_algorithmic": round(BYTES_PER_POINT * n * world / per / 1e9, 3)}
+
+
 def extras(zkg, torch, args, with_cpu):
     """Secondary legs of the metric, single GPU: NTT 2^20 (BASELINE configs[2]) and a full Groth16 prove on a zklaim-shaped
     system padded to m = 2^logm (configs[3]); not part of `value`."""
@@ -109,6 +146,10 @@ def extras(zkg, torch, args, with_cpu):
         out["ntt_2p20"]["cpu_baseline"] = {"seconds": round(cpu_dt, 3), "cores": 1, "kind": "port", "sample": "one forward 2^20 transform, oracle serial radix-2 FFT",
                                           "gpu_matches_cpu": bool(np.array_equal(d_a.cpu().numpy().view(np.uint64), ref))}
 
+    # BASELINE configs[4]'s per-GPU share (2^23 of the 2^26 points), and on request the whole 2^26 job on this one GPU (the strong-scaling reference)
+    out["msm_config5_share_2p23"] = msm_leg(zkg, torch, None, 23, 0, 5, False, 1)
+    if args.config5_reference:
+        out["msm_config5_single_gpu_2p26"] = msm_leg(zkg, torch, None, 26, 0, 3, False, 1)
     out["groth16_prove"] = prove_leg(zkg, torch, args, with_cpu, args.prove_logm)
     if args.prove_logm != 20 and not args.no_northstar:
         out["groth16_prove_2p20"] = prove_leg(zkg, torch, args, with_cpu, 20)                # the north star's 2^20-constraint case
@@ -199,6 +240,7 @@ def main():
                          "and owns every N-th Pippenger window; SURVEY.md section 8e's variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
+    ap.add_argument("--config5-reference", action="store_true", help="also time the whole 2^26-point MSM of BASELINE configs[4] on ONE GPU (6 GB of inputs; the strong-scaling reference for the 8 x 2^23 run)")
     ap.add_argument("--no-northstar", action="store_true", help="skip the second prove leg (37 payloads, m = 2^20: the north star's 2^20-constraint case)")
     ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 37 payloads (the north star's 2^20-constraint case)")
     args = ap.parse_args()
@@ -375,6 +417,14 @@ def main():
         if rank == 0 and int(pps[1].item()) == world:
             line["proofs_per_sec"] = round(float(pps[0].item()), 3)
             line["proofs_per_sec_note"] = f"{world} independent prover replicas (one per GPU), zklaim gadget, 8 payloads, m = 2^18"
+    if world > 1 and not args.no_extras:
+        # BASELINE configs[4]: 2^23 points per GPU (2^26 at 8 GPUs), same exchange; every rank takes part, rank 0 reports
+        try:
+            c5 = msm_leg(zkg, torch, dist, 23, 0x100 * rank, 3, use_dist, world)
+        except Exception as exc:
+            print("config-5 leg failed:", exc, file=sys.stderr); c5 = None
+        if rank == 0 and c5:
+            line["msm_config5"] = c5
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
