@@ -408,7 +408,7 @@ def main():
         # the prover does not shard (replicas only): every rank proves the same 8-payload credential on its own GPU
         # with its own resident key; the job's proofs/sec is the sum over ranks
         try:
-            g = prove_leg(zkg, torch, args, False)
+            g = prove_leg(zkg, torch, args, False, args.prove_logm)
             pps = torch.tensor([g["proofs_per_sec"], 1.0], dtype=torch.float64, device="cuda")
         except Exception as exc:                                     # never lose the headline line over the extra
             print("prove replicas failed:", exc, file=sys.stderr)
@@ -417,7 +417,7 @@ def main():
         if rank == 0 and int(pps[1].item()) == world:
             line["proofs_per_sec"] = round(float(pps[0].item()), 3)
             line["proofs_per_sec_note"] = f"{world} independent prover replicas (one per GPU), zklaim gadget, 8 payloads, m = 2^18"
-    if world > 1 and not args.no_extras:
+    if (world > 1 or (use_dist and os.environ.get("ZKG_BENCH_TEST_REPLICAS"))) and not args.no_extras:      # (the env switch lets one GPU rehearse this branch)
         # BASELINE configs[4]: 2^23 points per GPU (2^26 at 8 GPUs), same exchange; every rank takes part, rank 0 reports
         try:
             c5 = msm_leg(zkg, torch, dist, 23, 0x100 * rank, 3, use_dist, world)
