@@ -70,7 +70,8 @@ struct MsmGeom { uint32_t c, W, B, Wt, w0, ws; };
 struct SetLayout { size_t buckets, items, heavy, partials, folded, red_out; };     // elements per set in each per-set array
 template <class F> struct BaseView {
     const Affine<F> *p; size_t level_stride; const uint32_t *gather; uint32_t index_sub, B;
-    ZK_D Affine<F> load(uint32_t e, size_t gb) const {
+    template <bool PLAIN = false> ZK_D Affine<F> load(uint32_t e, size_t gb) const {
+        if constexpr (PLAIN) return p[e >> 1];            // a plain base set: nothing but the gather (the 2^20-point multi_exp's inner loop)
         uint32_t i = e >> 1;
         if (gather) i = gather[i];
         if (i < index_sub) return Affine<F>::inf();
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, co
 }
 
 // ---- 6. bucket accumulation (dominant kernel) -------------------------------------------------------------
-template <class F>
+template <class F, bool PLAIN>
 __global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
                                                        size_t lanes /* <= total buckets: the first `lanes` entries of order */, XYZZ<F> *buckets, HeavyItem *items,
                                                        HeavyBucket *heavy, uint32_t *counters /* per set: [0] items, [1] heavy buckets */, SetLayout L) {
@@ -453,11 +454,11 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, co
     XYZZ<F> acc = XYZZ<F>::inf();
     if (k < end) {
         uint32_t e = sorted[k];
-        Affine<F> p = bases.load(e, gb);
+        Affine<F> p = bases.template load<PLAIN>(e, gb);
         while (true) {
             Affine<F> cur = p; uint32_t ce = e;
             ++k;
-            if (k < end) { e = sorted[k]; p = bases.load(e, gb); }        // prefetch the next base under this addition
+            if (k < end) { e = sorted[k]; p = bases.template load<PLAIN>(e, gb); }        // prefetch the next base under this addition
             if (ce & 1u) cur.y = cur.y.neg();
             acc.madd(cur);
             if (k >= end) break;
@@ -736,10 +737,17 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     // an empty bucket, so its accumulation covers at most one lane per entry: a witness' ~10^5 entries over 2^19 buckets would otherwise
     // dispatch 8 K wavefronts that find nothing to do — on a chip they share with the H multi-exponentiation.
     const size_t lanes = gr.table ? std::min(total_buckets, n_entries_max) : total_buckets;
+    bool plain = !d_gather;
+    for (unsigned i = 0; i < ns; ++i) plain = plain && sets[i].level_stride == 0 && sets[i].index_sub == 0;
     if (time_it) g_dominant_timer.begin(s);
-    hipLaunchKernelGGL(k_bucket_accum<F>, dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
-                       views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
-                       gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
+    if (plain)
+        hipLaunchKernelGGL((k_bucket_accum<F, true>), dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
+                           views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
+                           gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
+    else
+        hipLaunchKernelGGL((k_bucket_accum<F, false>), dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
+                           views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
+                           gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(XYZZ<F>), s,
                        views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);

@@ -22,7 +22,7 @@ namespace zk {
 
 static constexpr int NTT_THREADS = 512;
 static const int NTT_TILE_LOG_FORCE = getenv("ZKG_NTT_TILE_LOG") ? atoi(getenv("ZKG_NTT_TILE_LOG")) : 0;   // tuning aid
-static constexpr int NTT_MAX_R = 8;
+static const int NTT_MAX_R = getenv("ZKG_NTT_MAX_R") ? atoi(getenv("ZKG_NTT_MAX_R")) : 8;                                // stages per pass (tuning aid)
 
 struct alignas(16) U4 { uint32_t a, b, c, d; };
 

@@ -14,6 +14,7 @@
 // sharing one digit sort); the prover randomness (r, s) is an explicit input.
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <algorithm>
 #include <chrono>
 #include <future>
 #include <cstdio>
@@ -358,7 +359,12 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         // the queries become per-window tables (level 0 is the query as uploaded).  A, B_g1, B_g2 and L are indexed by the same witness and
         // share one digit sort per proof, so they share one window size; H has its own.
         static const char *cw = getenv("ZKG_TABLE_C_W"), *ch = getenv("ZKG_TABLE_C_H");                  // tuning aids
-        const int c_w = cw ? atoi(cw) : table_window_bits(n + 1), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
+        // Witness queries: only the non-bit elements (~3 % of a credential's witness) reach the bucket method, so the window is sized for
+        // ~0.03 n entries per window — about two per bucket: c = log2(n) - 4.  Small bucket sets keep this latency-bound work light: the
+        // digit sort's LDS histogram is 2^(c-1) counters (16 KB at 8 payloads instead of the 128 KB of c = 16, which made its workgroups
+        // wait for an empty CU while the transforms ran), the fold and the reduction shrink with it.
+        int lg_n = 0; while (((size_t)1 << (lg_n + 1)) <= n + 1) ++lg_n;
+        const int c_w = cw ? atoi(cw) : std::min(16, std::max(8, lg_n - 4)), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
         DevBuf stage;
         auto table = [&](WindowTable &t, const uint64_t *src, size_t count, bool g2, int c) {
             const size_t bytes = count * (g2 ? 128 : 64);
