@@ -104,7 +104,7 @@ int zkg_ntt_dev(void *d_a, unsigned logN, int inverse, int coset, void *stream);
  *      r1cs_to_qap_instance_map / _witness_map call it with min_size = C + l + 1
  *      (inside snark.cpp:91 and :126): *m = the domain size, *is_step = 1 when it is a
  *      step_radix2_domain (m = 2^a + 2^b, b < a) instead of a basic_radix2_domain.
- *      zklaim's circuit lands on a step domain for 10 of its 20 payload counts
+ *      zklaim's circuit lands on a step domain for 11 of its 20 payload counts
  *      (e.g. 3 payloads: m = 2^16 + 2^15).
  *      zkg_ntt_domain: the same four transforms as zkg_ntt on the domain of size m,
  *      m = 2^k or 2^a + 2^b: libfqfft step_radix2_domain<Fr>::FFT / iFFT / cosetFFT /
@@ -194,10 +194,10 @@ int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint
                              const uint64_t r[4], const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */
 int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_out);
-/* per-stage device milliseconds of the last zkg_groth16_prove on this crs (the five MSMs run
- * concurrently on their own streams, so the entries overlap and do not add up to the total):
- * [0] R1CS mat-vec, [1] 7 NTTs + pointwise, [2] MSM A, [3] MSM B(G1), [4] MSM B(G2), [5] MSM H,
- * [6] MSM L, [7] wall-clock total incl. host assembly                                  */
+/* per-stage device milliseconds of the last zkg_groth16_prove on this crs (the stages run on their own streams, so the entries
+ * overlap and do not add up to the total): [0] R1CS mat-vec, [1] 7 NTTs + pointwise, [2] A / B(G1) / L over the non-bit witness
+ * elements (one batched job), [3] unused, [4] B(G2) over the same elements, [5] H, [6] unused, [7] wall-clock total incl. host
+ * assembly.  The flat sums over the witness elements equal to one run beside [2] and [4] on a stream of their own.               */
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
 
 /* ---- zklaim's credential circuit on the host: replaces protoboard + zklaim_gadget construction,

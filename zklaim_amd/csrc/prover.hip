@@ -360,11 +360,12 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
         // share one digit sort per proof, so they share one window size; H has its own.
         static const char *cw = getenv("ZKG_TABLE_C_W"), *ch = getenv("ZKG_TABLE_C_H");                  // tuning aids
         // Witness queries: only the non-bit elements (~3 % of a credential's witness) reach the bucket method, so the window is sized for
-        // ~0.03 n entries per window — about two per bucket: c = log2(n) - 4.  Small bucket sets keep this latency-bound work light: the
-        // digit sort's LDS histogram is 2^(c-1) counters (16 KB at 8 payloads instead of the 128 KB of c = 16, which made its workgroups
-        // wait for an empty CU while the transforms ran), the fold and the reduction shrink with it.
+        // ~0.03 n entries per window — a few per bucket: c = log2(n) - 5, at most 14 (measured flat between 10 and 14 at 8 and 37 payloads,
+        // 5 % slower at 16).  Small bucket sets keep this latency-bound work light: the digit sort's LDS histogram is 2^(c-1) counters
+        // (8 KB at 8 payloads instead of the 128 KB of c = 16, which made its workgroups wait for an empty CU while the transforms ran),
+        // the fold and the reduction shrink with it.
         int lg_n = 0; while (((size_t)1 << (lg_n + 1)) <= n + 1) ++lg_n;
-        const int c_w = cw ? atoi(cw) : std::min(16, std::max(8, lg_n - 4)), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
+        const int c_w = cw ? atoi(cw) : std::min(14, std::max(8, lg_n - 5)), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
         DevBuf stage;
         auto table = [&](WindowTable &t, const uint64_t *src, size_t count, bool g2, int c) {
             const size_t bytes = count * (g2 ? 128 : 64);
@@ -448,7 +449,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — ~3 % of a credential's
     // witness — through the bucket method as a gathered subset.  The count of "the rest" sizes the launches, so a helper thread waits
     // for the split (event 0), reads it and queues the four witness streams' work while this thread queues the critical path.
-    auto witness_jobs = std::async(std::launch::async, [&]() -> int {
+    auto witness_fn = [&]() -> int {
         ZK_HIP(hipEventSynchronize(S.ev[0]));
         const size_t listed = S.flag_host[1];
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
@@ -475,7 +476,9 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
             if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
         }
         return ZKG_OK;
-    });
+    };
+    std::future<int> witness_jobs;
+    if (!g_serial_msm) witness_jobs = std::async(std::launch::async, witness_fn);
     int rc = compute_h_transforms(crs, S);
     lap(S, "transforms enqueued");
     // H: uniformly random scalars, follows the transforms in stream order
@@ -487,7 +490,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
-    const int rc_w = witness_jobs.get();
+    const int rc_w = g_serial_msm ? witness_fn() : witness_jobs.get();          // (profiling aid: every job alone on the chip, one after the other)
     lap(S, "msm jobs enqueued");
     return rc == ZKG_OK ? rc_w : rc;
 }
