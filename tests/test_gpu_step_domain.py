@@ -132,3 +132,29 @@ def test_prove_zklaim_three_payloads_vs_oracle(zkg, oracle):
     rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, arrays), w, rs[0], rs[1], chunks=oracle.num_threads())
     assert rc_o == 0 and proof_o == proof
     crs.free(); kp.free()
+
+
+def test_prove_step_domain_with_large_ratio(zkg, oracle):
+    """big / small = 64: the fold / unfold walks are cut into 16-index chunks with a second summing pass (k_step_*_chunk / _finish),
+    batched over the prover's three vectors.  A zklaim-shaped system of 2^12 - l - 1 rows plus 40 padding rows lands on
+    step_radix2_domain(2^12 + 2^6); H coefficients and proof bytes against the oracle."""
+    from zklaim_amd import synth
+    n, l, A, B, C, w = synth.zklaim_shaped(12, num_inputs=5, seed=19)
+    pad = 40
+    A = (np.concatenate([A[0], A[0][-1] + np.arange(1, pad + 1, dtype=np.uint32)]), np.concatenate([A[1], np.zeros(pad, np.uint32)]),
+         np.concatenate([A[2], np.tile(arr([1], R), (pad, 1))]))                                 # 1 * 0 = 0
+    B = (np.concatenate([B[0], np.full(pad, B[0][-1], np.uint32)]), B[1], B[2])
+    C = (np.concatenate([C[0], np.full(pad, C[0][-1], np.uint32)]), C[1], C[2])
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    assert oracle.r1cs_is_satisfied(ocs, w)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x51))
+    m = crs_arrays["m"]
+    assert m == (1 << 12) + (1 << 6) and zkg.evaluation_domain_size(len(A[0]) - 1 + l + 1) == (m, True)
+    rs = random_fr_canonical(2, 0x52)
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0], rs[1])
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, (m - 1).bit_length(), keep, domain_size=m))
+    assert np.array_equal(crs.qap_witness_h(w), oracle.qap_witness_h(ocs, w, m))
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc_o == 0 and rc == 0 and proof == proof_o
+    crs.free()

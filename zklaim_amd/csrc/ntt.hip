@@ -328,6 +328,63 @@ __global__ __launch_bounds__(256) void k_step_unfold(StepArgs A) {
     a[i] = lo.normalized(); a[A.big + i] = hi.normalized();
 }
 
+// big/small > STEP_J: the walk over the big/small indices congruent to i is cut into chunks of STEP_J, one lane per (i, chunk); the chunks'
+// partial sums of w^k d_k land in `part` (chunk-major) and a second pass adds them up.  (At 19 payloads zklaim's domain is 2^19 + 2^11:
+// 2048 lanes walking 256 indices each made that proof the outlier of the k = 1..20 sweep.)
+static constexpr uint32_t STEP_J = 16;
+__global__ __launch_bounds__(256) void k_step_fold_chunk(StepArgs A, Fr *part, size_t part_stride) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nch = A.compr / STEP_J;
+    if (t >= A.small * nch) return;
+    const size_t i = t % A.small, ch = t / A.small;
+    Fr *a = A.a + (size_t)blockIdx.y * A.stride;
+    Fr hi = Fr::zero();
+    if (ch == 0) { hi = a[A.big + i]; if (A.g) hi = hi * A.g[A.big + i]; }
+    Fr e = Fr::zero();
+    for (uint32_t jj = 0; jj < STEP_J; ++jj) {
+        const size_t j = ch * STEP_J + jj, k = i + j * A.small;
+        Fr x = a[k];
+        if (A.g) x = x * A.g[k];
+        Fr c = x, d = x;
+        if (j == 0) { c = x + hi; d = x - hi; }
+        a[k] = c.normalized();
+        e += A.w[k] * d;
+    }
+    part[(size_t)blockIdx.y * part_stride + ch * A.small + i] = e.normalized();
+}
+__global__ __launch_bounds__(256) void k_step_fold_finish(StepArgs A, const Fr *part, size_t part_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nch = A.compr / STEP_J;
+    if (i >= A.small) return;
+    Fr e = Fr::zero();
+    for (size_t ch = 0; ch < nch; ++ch) e += part[(size_t)blockIdx.y * part_stride + ch * A.small + i];
+    A.a[(size_t)blockIdx.y * A.stride + A.big + i] = e.normalized();
+}
+__global__ __launch_bounds__(256) void k_step_unfold_chunk(StepArgs A, Fr *part, size_t part_stride) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nch = A.compr / STEP_J;
+    if (t >= A.small * nch) return;
+    const size_t i = t % A.small, ch = t / A.small;
+    Fr *a = A.a + (size_t)blockIdx.y * A.stride;
+    Fr sum = Fr::zero();
+    for (uint32_t jj = 0; jj < STEP_J; ++jj) {
+        const size_t j = ch * STEP_J + jj, k = i + j * A.small;
+        if (j == 0) continue;                                   // the two overlapping coefficients are solved for in the finishing pass
+        Fr x = a[k];
+        sum += x * A.w[k];
+        if (A.g) a[k] = (x * A.g[k]).normalized();
+    }
+    part[(size_t)blockIdx.y * part_stride + ch * A.small + i] = sum.normalized();
+}
+__global__ __launch_bounds__(256) void k_step_unfold_finish(StepArgs A, const Fr *part, size_t part_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nch = A.compr / STEP_J;
+    if (i >= A.small) return;
+    Fr *a = A.a + (size_t)blockIdx.y * A.stride;
+    Fr u1 = a[A.big + i];
+    for (size_t ch = 0; ch < nch; ++ch) u1 -= part[(size_t)blockIdx.y * part_stride + ch * A.small + i];
+    Fr u1h = u1 * A.winv_half[i], u0h = a[i] * A.half;
+    Fr lo = u0h + u1h, hi = u0h - u1h;
+    if (A.g) { lo = lo * A.g[i]; hi = hi * A.g[A.big + i]; }
+    a[i] = lo.normalized(); a[A.big + i] = hi.normalized();
+}
+
 int StepDomain::init(const DomainShape &sh, hipStream_t s) {
     shape = sh;
     const size_t big = sh.big, small = sh.small, m = sh.m;
@@ -377,16 +434,21 @@ int step_ntt_run(StepDomain *d, Fr *a, bool inverse, bool coset, hipStream_t s, 
     A.a = a; A.w = d->w.as<Fr>(); A.winv_half = d->winv_half.as<Fr>(); A.big = big; A.small = small; A.stride = stride;
     A.compr = (uint32_t)(big / small); A.half = d->half;
     dim3 grid((unsigned)((small + 255) / 256), batch);
+    const bool chunked = A.compr > STEP_J;                     // compr is a power of two: a multiple of STEP_J then
+    dim3 grid_ch((unsigned)((small * (A.compr / STEP_J) + 255) / 256), batch);
+    Fr *part = scratch;                                        // big / STEP_J elements per vector: the transforms' scratch is idle around them
     if (!inverse) {
         A.g = coset ? d->g_pow.as<Fr>() : nullptr;
-        hipLaunchKernelGGL(k_step_fold, grid, dim3(256), 0, s, A);
+        if (chunked) { hipLaunchKernelGGL(k_step_fold_chunk, grid_ch, dim3(256), 0, s, A, part, stride); hipLaunchKernelGGL(k_step_fold_finish, grid, dim3(256), 0, s, A, part, stride); }
+        else hipLaunchKernelGGL(k_step_fold, grid, dim3(256), 0, s, A);
         if (ntt_run_ex(d->dbig, a, false, nullptr, nullptr, nullptr, s, scratch, batch, stride)) return ZKG_ERROR;
         if (ntt_run_ex(d->dsmall, a + big, false, nullptr, nullptr, nullptr, s, scratch + big, batch, stride)) return ZKG_ERROR;
     } else {
         if (ntt_run_ex(d->dbig, a, true, nullptr, nullptr, &d->big_inv, s, scratch, batch, stride)) return ZKG_ERROR;
         if (ntt_run_ex(d->dsmall, a + big, true, nullptr, nullptr, &d->small_inv, s, scratch + big, batch, stride)) return ZKG_ERROR;
         A.g = coset ? d->ginv_pow.as<Fr>() : nullptr;
-        hipLaunchKernelGGL(k_step_unfold, grid, dim3(256), 0, s, A);
+        if (chunked) { hipLaunchKernelGGL(k_step_unfold_chunk, grid_ch, dim3(256), 0, s, A, part, stride); hipLaunchKernelGGL(k_step_unfold_finish, grid, dim3(256), 0, s, A, part, stride); }
+        else hipLaunchKernelGGL(k_step_unfold, grid, dim3(256), 0, s, A);
     }
     if (hipGetLastError() != hipSuccess) { set_error("step ntt launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
