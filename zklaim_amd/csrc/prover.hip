@@ -433,6 +433,8 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
 
 // ---- one proof = prove_enqueue (everything the GPU does, queued without waiting) + prove_finish (host tails, assembly, bytes)
 static const bool g_dbg_timing = getenv("ZKG_DEBUG_TIMING") != nullptr, g_serial_msm = getenv("ZKG_SERIAL_MSM") != nullptr;
+// ZKG_WITNESS_START (tuning aid): which event the witness streams wait for — 0 the split (default), 1 the mat-vec, 2 the transforms
+static const int g_witness_start = [] { const char *e = getenv("ZKG_WITNESS_START"); int v = e ? atoi(e) : 0; return v >= 0 && v <= 2 ? v : 0; }();
 static void lap(const ProverSlot &S, const char *what) {
     if (g_dbg_timing) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
 }
@@ -455,12 +457,14 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
         const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
         const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))}, b2 = table_set(crs->B_g2, 0);
+        // ZKG_WITNESS_START (tuning aid): which event the witness streams wait for — 0 the split (default), 1 the mat-vec, 2 the transforms
+        hipEvent_t go = S.ev[g_witness_start];
         {
             hipStream_t js = msm_job_stream(S.job_w2);                         // G2 first: the longest chains
-            ZK_HIP(hipStreamWaitEvent(S.stream_o, S.ev[0], 0));
+            ZK_HIP(hipStreamWaitEvent(S.stream_o, go, 0));
             if (ones_sum_launch(S.ones_g2, &b2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
             (void)hipEventRecord(S.ev[10], S.stream_o);                        // the G2 sum has landed (the G1 sums follow on the same stream)
-            ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+            ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[6], js);
             if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
             (void)hipEventRecord(S.ev[7], js);
@@ -469,7 +473,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         {
             hipStream_t js = msm_job_stream(S.job_w1);
             if (ones_sum_launch(S.ones_g1, g1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
-            ZK_HIP(hipStreamWaitEvent(js, S.ev[0], 0));
+            ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[4], js);
             if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
             (void)hipEventRecord(S.ev[5], js);
@@ -478,7 +482,8 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         return ZKG_OK;
     };
     std::future<int> witness_jobs;
-    if (!g_serial_msm) witness_jobs = std::async(std::launch::async, witness_fn);
+    const bool helper = !g_serial_msm && g_witness_start == 0;                  // a later start event must have been recorded before it is waited for
+    if (helper) witness_jobs = std::async(std::launch::async, witness_fn);
     int rc = compute_h_transforms(crs, S);
     lap(S, "transforms enqueued");
     // H: uniformly random scalars, follows the transforms in stream order
@@ -490,7 +495,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
-    const int rc_w = g_serial_msm ? witness_fn() : witness_jobs.get();          // (profiling aid: every job alone on the chip, one after the other)
+    const int rc_w = helper ? witness_jobs.get() : witness_fn();          // (profiling aid: every job alone on the chip, one after the other)
     lap(S, "msm jobs enqueued");
     return rc == ZKG_OK ? rc_w : rc;
 }
