@@ -121,3 +121,18 @@ def test_c_caller_links_the_seam(zkg, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr[-500:])
     assert out.returncode == 0 and "seam demo ok" in out.stdout
+
+
+def test_c_caller_of_the_multi_gpu_entry_points(zkg, tmp_path):
+    """tests/c/multi_gpu_demo.c: zkg_init_multi / zkg_msm_g1_shards_upload / zkg_msm_g1_multi called from plain C (what zklaim.c's
+    single-threaded front-end could call); three shards — on three GPUs when the box has them, on device 0 otherwise"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "multi_gpu_demo")
+    so_dir = os.path.join(root, "zklaim_amd")
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "multi_gpu_demo.c"), "-o", exe,
+                           os.path.join(so_dir, "libzkg.so"), "-Wl,-rpath," + so_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr[-500:])
+    assert out.returncode == 0 and "ok" in out.stdout
