@@ -149,3 +149,47 @@ def test_prove_sparse_witness_matches_dense(zkg):
     rc4, again = crs.prove(w, rs[0], rs[1])
     assert rc4 == 0 and again == dense
     crs.free(); kp.free()
+
+
+def _trivial_system(values):
+    """x_i * 1 = x_i for every variable: satisfied by ANY assignment, so the witness can be shaped at will (one public input)"""
+    n = len(values)
+    rp = np.arange(n + 1, dtype=np.uint32); cols = np.arange(1, n + 1, dtype=np.uint32)
+    one = np.tile(arr([1], R), (n, 1))
+    A = (rp, cols, one); B = (rp, np.zeros(n, np.uint32), one); C = (rp, cols, one)
+    return n, 1, A, B, C, arr(values, R)
+
+
+@pytest.mark.parametrize("shape", ["all_bits", "no_bits", "repeated_values", "all_zero_but_one"])
+def test_prove_witness_split_edge_cases(zkg, oracle, shape):
+    """the prover's multi_exp_with_mixed_addition split at its edges: a witness of bits only (nothing reaches the bucket method), one
+    with no bit at all (everything does), one whose non-bit values repeat 700 times (one heavy bucket per window, through the gathered
+    table path) and an almost empty one — proof bytes against the oracle each time"""
+    rng = np.random.default_rng(17)
+    n = 3000
+    if shape == "all_bits":
+        vals = [int(x) for x in rng.integers(0, 2, n)]
+    elif shape == "no_bits":
+        vals = [int.from_bytes(rng.bytes(31), "little") % (R - 2) + 2 for _ in range(n)]
+    elif shape == "repeated_values":
+        rep = int.from_bytes(rng.bytes(31), "little") % R
+        vals = [rep if i % 4 == 0 else (int(rng.integers(0, 2)) if i % 4 < 3 else int.from_bytes(rng.bytes(31), "little") % R) for i in range(n)]
+    else:
+        vals = [0] * n; vals[1234] = 5
+    n, l, A, B, C, w = _trivial_system(vals)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    assert oracle.r1cs_is_satisfied(ocs, w)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x61))
+    rs = random_fr_canonical(2, 0x62)
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0], rs[1])
+    m = crs_arrays["m"]
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, (m - 1).bit_length(), keep, domain_size=m))
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc_o == 0 and rc == 0 and proof == proof_o, shape
+    one = arr([1], R)[0]
+    tags = np.where(~w.any(axis=1), 0, np.where((w == one).all(axis=1), 1, 2)).astype(np.uint8)
+    idx = np.flatnonzero(tags == 2).astype(np.uint32)
+    rc_s, proof_s = crs.prove_sparse(tags, idx, w[idx], rs[0], rs[1])
+    assert rc_s == 0 and proof_s == proof, shape
+    crs.free()

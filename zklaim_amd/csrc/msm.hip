@@ -24,11 +24,20 @@
 //                      Buckets longer than heavy_t leave this kernel: they are cut into 512-entry parts
 //                      summed by one wavefront each (k_heavy_parts) and merged per bucket by an LDS tree
 //                      (k_heavy_merge), so no lane ever walks a long list alone
-//   7. k_bucket_reduce sum_b (b+1)*B_b per chunk of 512 or 2048 buckets: per-lane running sums, then an LDS suffix
+//   7. k_bucket_reduce sum_b (b+1)*B_b per chunk of 128 ... 2048 buckets: per-lane running sums, then an LDS suffix
 //                      scan + tree reduction across the workgroup; every addition is shared by a DPP quad
 //   8. host            per-window chunk combine and the c-doublings Horner across windows
 // Zero scalars are dropped in step 1 and scalars equal to one simply land in bucket (window 0, digit 1),
 // a "heavy" bucket: the effect of libff's multi_exp_with_mixed_addition prefilter without a special case.
+//
+// The prover's resident key adds two things (prover.hip drives them):
+//   * per-window tables (window_table_build_*): level w holds 2^(c w) P_i, so a digit of any window weighs the same — step 6 gathers from
+//     the digit's level, k_bucket_fold sums the W bucket sets bucket-wise (LDS tree over the windows), step 7 runs ONCE over 2^(c-1)
+//     buckets and step 8 has no doubling left;
+//   * the witness split (witness_classify, ones_sum_launch): multi_exp_with_mixed_addition as libff does it — zeros skipped, bases whose
+//     scalar is one added flat (k_ones_sum, k_sum_partials), the remaining scalars through steps 1-8 as a gathered subset, several base
+//     sets (A, B_g1, L) per launch (blockIdx.y).
+// Also here: the generator's fixed-base batch (k_fixed_table, k_fixed_base: byte windows, in-lane batched normalisation).
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
@@ -48,8 +57,10 @@ template <class F> struct RedGeom { static constexpr int LANES_LOG = sizeof(F) =
 // buckets per logical lane in the running-sum step, 2^L_LOG: the kernel is a dependency chain of 2(L-1) + 2 log2(128) + 2
 // additions but does (2(L-1) + 14)/L additions per bucket, so small bucket sets (latency-bound: the prover's witness MSMs)
 // take L = 4 and large ones (work-bound: 2^19 buckets at N = 2^20) take L = 16.
-static constexpr int RED_L_LOG_SMALL = 2, RED_L_LOG_LARGE = 4;
-static constexpr size_t RED_LARGE_BUCKETS = (size_t)1 << 18;
+static constexpr int RED_L_LOG_TINY = 0, RED_L_LOG_SMALL = 2, RED_L_LOG_LARGE = 4;
+// up to 2^16 buckets one bucket per logical lane still is a single round of workgroups (512 of them for G1): the chain is 2 log2(LANES) + 3
+// additions, 17 instead of 23 for G1 — every table launch of the prover (one folded bucket set of <= 2^15 buckets) is in this class
+static constexpr size_t RED_SMALL_BUCKETS = (size_t)1 << 16, RED_LARGE_BUCKETS = (size_t)1 << 18;
 static constexpr int MAX_C = 16;             // LDS histogram: 2^(c-1) u32 counters <= 128 KiB
 static constexpr uint32_t HEAVY_S = 512;     // entries per heavy part (one wavefront sums one part)
 static constexpr uint32_t HEAVY_T_MAX = 1024;
@@ -714,11 +725,16 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     const MsmGeom g = job->g; const size_t n = job->n, total_buckets = (size_t)g.W * g.B; const unsigned ns = (unsigned)gr.nsets;
     hipStream_t s = job->stream;
     size_t n_entries_max = n * g.W;
-    size_t max_heavy = n_entries_max / 4 + 1, max_items = n_entries_max / 4 + n_entries_max / HEAVY_S + 2;     // worst case of the device-side threshold (>= 4)
+    // worst case of the device-side threshold: a heavy bucket holds more than 8 entries (G1; 4 for G2), so there are fewer than
+    // entries / 8 (entries / 4) of them and never more than there are buckets; each is cut into ceil(len / 512) parts
+    const size_t max_heavy = std::min(total_buckets, n_entries_max / (sizeof(F) != sizeof(Fq) ? 4 : 8)) + 1,
+                 max_items = max_heavy + n_entries_max / HEAVY_S + 1;
     typedef RedGeom<F> RG;
     gr.table = sets[0].level_stride != 0;
     gr.red_windows = gr.table ? 1 : g.W;                             // a table's windows are folded into one bucket set first
-    const int red_l_log = (size_t)gr.red_windows * g.B >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : RED_L_LOG_SMALL;
+    const size_t red_buckets = (size_t)gr.red_windows * g.B;
+    static const char *force_l = getenv("ZKG_RED_L_LOG");                                                  // tuning aid: 0, 2 or 4
+    const int red_l_log = force_l ? atoi(force_l) : red_buckets >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : red_buckets > RED_SMALL_BUCKETS ? RED_L_LOG_SMALL : RED_L_LOG_TINY;
     gr.chunk_log = RG::LANES_LOG + red_l_log;
     gr.cpw = (g.B + (1u << gr.chunk_log) - 1) >> gr.chunk_log; gr.nred = (size_t)gr.red_windows * gr.cpw;
     SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 2;
@@ -764,8 +780,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if (red_l_log == RED_L_LOG_LARGE)
         hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
-    else
+    else if (red_l_log == RED_L_LOG_SMALL)
         hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+                           red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
+    else
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_TINY>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
     ZK_HIP(hipMemcpyAsync(gr.host_red, gr.red_out.p, ns * L.red_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
@@ -1117,6 +1136,7 @@ static void fixed_tables_release() {
 
 int msm_configure() {
     bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
