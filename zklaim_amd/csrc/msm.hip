@@ -478,15 +478,25 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, co
     buckets[gb] = acc.normalized();
 }
 
+// A point in LDS, padded to 144 B (G1) / 272 B (G2): at the natural 128 / 256-byte stride consecutive points start on the same four banks.
+// Measured effect: k_bucket_reduce 363 -> 354 us at 2^19 buckets — the kernels that use it are bound by the multiplications of their
+// addition chains (two wavefronts per SIMD: 1.16 us per dependent product), not by the LDS port.
+template <class F> struct alignas(16) LdsPoint {
+    XYZZ<F> p; uint32_t pad[4];
+    ZK_D LdsPoint &operator=(const XYZZ<F> &v) { p = v; return *this; }
+    ZK_D operator const XYZZ<F> &() const { return p; }
+    ZK_D XYZZ<F> normalized() const { return p.normalized(); }
+};
+
 // LDS tree reduction of seg[0..n) into seg[0] by `nthreads` threads (tid = 0..nthreads-1, n a power of two <= nthreads;
 // every thread of the group must call it; barrier() synchronises the group).  Levels with at most nthreads/4 pairs share
 // each addition across a DPP quad (nthreads is a multiple of 64, so quads never straddle groups).
 template <class F, class Barrier>
-ZK_D void lds_tree_reduce(XYZZ<F> *seg, uint32_t n, uint32_t tid, uint32_t nthreads, Barrier barrier) {
+ZK_D void lds_tree_reduce(LdsPoint<F> *seg, uint32_t n, uint32_t tid, uint32_t nthreads, Barrier barrier) {
     for (uint32_t d = n / 2; d >= 1; d >>= 1) {
         if (4 * d <= nthreads) {
             uint32_t t = tid >> 2, q = tid & 3;
-            if (t < d) { XYZZ<F> a = seg[t]; xyzz_add_quad(a, seg[t + d], q); if (q == 0) seg[t] = a; }
+            if (t < d) { XYZZ<F> a = seg[t]; xyzz_add_quad(a, seg[t + d].p, q); if (q == 0) seg[t] = a; }
         } else if (tid < d) { XYZZ<F> a = seg[tid]; a.add(seg[tid + d]); seg[tid] = a; }
         barrier();
     }
@@ -497,7 +507,7 @@ template <class F>
 __global__ __launch_bounds__(256) void k_heavy_parts(const ViewSet<F> views, const uint32_t *sorted, const HeavyItem *items,
                                                       const uint32_t *counters, XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);            // 256 points
     const uint32_t set = blockIdx.y;
     const BaseView<F> bases = views.v[set];
     items += set * L.items; partials += set * L.partials; buckets += set * L.buckets;
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const ViewSet<F> views, con
 template <class F>
 __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, const uint32_t *counters, const XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);
     const uint32_t set = blockIdx.y;
     heavy += set * L.heavy; partials += set * L.partials; buckets += set * L.buckets;
     const uint32_t n_heavy = counters[2 * set + 1], t = threadIdx.x;
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
                                                                        size_t in_set_stride, size_t out_set_stride) {
     constexpr int RED_LANES = RedGeom<F>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);              // 2 * RED_LANES points
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);              // 2 * RED_LANES points
     const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;          // logical lane, position in its quad
     const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
     const XYZZ<F> *X = buckets + blockIdx.y * in_set_stride + (size_t)w * B;
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
     for (uint32_t d = 1; d < RED_LANES; d <<= 1) {
         if (q == 0) sh[t] = Q;
         __syncthreads();
-        if (t + d < RED_LANES) xyzz_add_quad(Q, sh[t + d], q);
+        if (t + d < RED_LANES) xyzz_add_quad(Q, sh[t + d].p, q);
         __syncthreads();
     }
     // sum_t t*S_t = sum_{t>=1} Q_t ; tree-reduce Q (t>=1) in sh[0..), T0 in sh[RED_LANES..)
@@ -580,17 +590,17 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
     if (q == 0) { sh[t] = (t >= 1) ? Q : XYZZ<F>::inf(); sh[RED_LANES + t] = T0; }
     __syncthreads();
     for (uint32_t d = RED_LANES / 2; d >= 1; d >>= 1) {
-        if (t < d) { XYZZ<F> a = sh[t]; xyzz_add_quad(a, sh[t + d], q); if (q == 0) sh[t] = a; }
+        if (t < d) { XYZZ<F> a = sh[t]; xyzz_add_quad(a, sh[t + d].p, q); if (q == 0) sh[t] = a; }
         else if (t >= RED_LANES / 2 && t < RED_LANES / 2 + d) {
             uint32_t u = RED_LANES + (t - RED_LANES / 2);
-            XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + d], q); if (q == 0) sh[u] = a;
+            XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + d].p, q); if (q == 0) sh[u] = a;
         }
         __syncthreads();
     }
     if (t == 0) {
         XYZZ<F> E = sh[0];
         for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();            // * RED_L
-        xyzz_add_quad(E, sh[RED_LANES], q);
+        xyzz_add_quad(E, sh[RED_LANES].p, q);
         if (q == 0) { out[2 * (size_t)blockIdx.x] = P.normalized(); out[2 * (size_t)blockIdx.x + 1] = E.normalized(); }
     }
 }
@@ -603,7 +613,7 @@ static constexpr uint32_t FOLD_THREADS = 256;
 template <class F>
 __global__ __launch_bounds__(FOLD_THREADS) void k_bucket_fold(const XYZZ<F> *buckets, const uint32_t *counts, uint32_t W, uint32_t B, uint32_t fold_b_log, XYZZ<F> *out, SetLayout L) {
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // FOLD_THREADS points: [window slot][bucket]
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);            // FOLD_THREADS points: [window slot][bucket]
     const uint32_t t = threadIdx.x, FB = 1u << fold_b_log, slots = FOLD_THREADS >> fold_b_log;     // window slots held at once (a power of two)
     const uint32_t bl = t & (FB - 1), slot = t >> fold_b_log, b = blockIdx.x * FB + bl;
     buckets += blockIdx.y * L.buckets; out += blockIdx.y * L.folded;
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_bucket_fold(const XYZZ<F> *buc
         const uint32_t pairs = d << fold_b_log;
         if (4 * pairs <= FOLD_THREADS) {
             const uint32_t u = t >> 2, q = t & 3;
-            if (u < pairs) { XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + pairs], q); if (q == 0) sh[u] = a; }
+            if (u < pairs) { XYZZ<F> a = sh[u]; xyzz_add_quad(a, sh[u + pairs].p, q); if (q == 0) sh[u] = a; }
         } else if (t < pairs) { XYZZ<F> a = sh[t]; a.add(sh[t + pairs]); sh[t] = a; }
         __syncthreads();
     }
@@ -663,7 +673,7 @@ __global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_
 template <class F>
 __global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const uint8_t *tags, size_t n1, XYZZ<F> *partials) {
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);            // 256 points
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);            // 256 points
     const Affine<F> *bases = views.v[blockIdx.y].p; const uint32_t index_sub = views.v[blockIdx.y].index_sub;
     partials += (size_t)blockIdx.y * (gridDim.x + 1);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const 
 template <class F>
 __global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uint32_t count) {        // per set: partials[0..count) -> partials[count]
     extern __shared__ unsigned char red_smem[];
-    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(red_smem);
+    LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);
     XYZZ<F> *partials = partials_all + (size_t)blockIdx.x * (count + 1), *out = partials + count;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t i = threadIdx.x; i < count; i += 256) acc.add(partials[i]);
@@ -765,26 +775,26 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                            views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
                            gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     if (time_it) g_dominant_timer.end(s);
-    hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(XYZZ<F>), s,
+    hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
                        views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
-    hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS, ns), dim3(256), 256 * sizeof(XYZZ<F>), s,
+    hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
                        gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
     const XYZZ<F> *red_in = buckets; size_t in_stride = L.buckets;
     if (gr.table) {
         uint32_t slots = 1; while (slots < g.W && slots < 32) slots <<= 1;                // window slots per workgroup: W rounded up to a power of two (<= 32)
         uint32_t fold_b_log = 0; while ((FOLD_THREADS >> (fold_b_log + 1)) >= slots) ++fold_b_log;
-        hipLaunchKernelGGL(k_bucket_fold<F>, dim3((g.B + (1u << fold_b_log) - 1) >> fold_b_log, ns), dim3(FOLD_THREADS), FOLD_THREADS * sizeof(XYZZ<F>), s,
+        hipLaunchKernelGGL(k_bucket_fold<F>, dim3((g.B + (1u << fold_b_log) - 1) >> fold_b_log, ns), dim3(FOLD_THREADS), FOLD_THREADS * sizeof(LdsPoint<F>), s,
                            buckets, job->counts.as<uint32_t>(), g.W, g.B, fold_b_log, gr.folded.as<XYZZ<F>>(), L);
         red_in = gr.folded.as<XYZZ<F>>(); in_stride = L.folded;
     }
     if (red_l_log == RED_L_LOG_LARGE)
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(LdsPoint<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     else if (red_l_log == RED_L_LOG_SMALL)
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_SMALL>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(LdsPoint<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     else
-        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_TINY>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(XYZZ<F>), s,
+        hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_TINY>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(LdsPoint<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
     ZK_HIP(hipMemcpyAsync(gr.host_red, gr.red_out.p, ns * L.red_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
@@ -1028,8 +1038,8 @@ static int ones_sum_launch_t(OnesSum &o, const MsmBases *sets, int nsets, const 
     XYZZ<F> *part = o.partials.as<XYZZ<F>>();
     ViewSet<F> views;
     for (int i = 0; i < MSM_MAX_SETS; ++i) { const MsmBases &b = sets[i < nsets ? i : 0]; views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), 0, nullptr, b.index_sub, 1}; }
-    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(XYZZ<F>), s, views, d_tags, n1, part);
-    hipLaunchKernelGGL(k_sum_partials<F>, dim3((unsigned)nsets), dim3(256), 256 * sizeof(XYZZ<F>), s, part, blocks);
+    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, views, d_tags, n1, part);
+    hipLaunchKernelGGL(k_sum_partials<F>, dim3((unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, part, blocks);
     if (hipGetLastError() != hipSuccess) { set_error("ones-sum launch failed"); return ZKG_ERROR; }
     for (int i = 0; i < nsets; ++i)
         ZK_HIP(hipMemcpyAsync((char *)o.host + (size_t)i * sizeof(XYZZ<F>), part + (size_t)i * (blocks + 1) + blocks, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
@@ -1135,14 +1145,14 @@ static void fixed_tables_release() {
 }
 
 int msm_configure() {
-    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_bucket_fold<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_THREADS * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(G2)) == hipSuccess;
+    bool ok = hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce<Fq2, RED_L_LOG_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RedGeom<Fq2>::LANES * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_fold<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_THREADS * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
