@@ -6,6 +6,9 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/refresh
 mkdir -p $OUT
+# counters first: bench.py reports roofline.traffic only from a pmc_traffic.json collected on the kernel sources it runs
+bash tools/pmc_collect.sh || exit 1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 timeout -k 10 700 python bench.py > $OUT/r2_bench.json 2> $OUT/bench.err || exit 1
 echo "bench done" && tail -c 300 $OUT/r2_bench.json
 # headline MSM: per-kernel durations of the same command (no CPU legs, no extras)
@@ -23,8 +26,6 @@ for k in 8 37; do
   cp $OUT/kstats_prove_serial_k$k/p_kernel_stats.csv $OUT/r2_prove_k${k}_serial_kernel_stats.csv
   REPS=30 timeout -k 10 200 python3 tools/zklaim_prove_profile.py $k | tail -1 > $OUT/r2_prove_k${k}_timing.txt
 done
-bash tools/pmc_collect.sh || exit 1
-cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # NTT counters (own pass, kernel-trace only beside --pmc)
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/ntt_pmc -o p -- python3 tools/ntt_profile.py 20 5 > $OUT/ntt_pmc.log 2>&1 || exit 1
 cp $OUT/ntt_pmc/p_counter_collection.csv $OUT/r2_ntt_2p20_pmc.csv
