@@ -351,6 +351,7 @@ int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t
 //      its own (hipSetDevice is per thread), the shards run the complete single-GPU Pippenger concurrently, and the partial points — 96
 //      bytes each — are added on the host.  There is no data-path collective: RCCL has no elliptic-curve reduction, and a sum of
 //      ndev points is not worth a kernel.  (The one-process-per-GPU form of the same exchange is zklaim_amd/dist.py over RCCL.)
+namespace { struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); } }; }   // also on an exception
 struct zkg_msm_shards {
     struct Shard { int device = 0; size_t first = 0, n = 0; DevBuf bases, scalars; MsmJob *job = nullptr; };
     std::vector<Shard> shards; size_t n = 0;
@@ -371,13 +372,16 @@ int zkg_init_multi(const int *devices, int ndev) {
     return ZKG_OK;
 }
 
-zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const int *devices, int ndev) {
+static zkg_msm_shards *zkg_msm_g1_shards_upload_impl(const uint64_t *bases, size_t n, const int *devices, int ndev) {
     if (g_device < 0) { set_error("zkg_init not called"); return nullptr; }
     if ((n && !bases) || !devices || ndev < 1 || ndev > 64) { set_error("zkg_msm_g1_shards_upload: bad argument"); return nullptr; }
-    zkg_msm_shards *h = new zkg_msm_shards();
+    std::unique_ptr<zkg_msm_shards, void (*)(zkg_msm_shards *)> holder(new zkg_msm_shards(), zkg_msm_g1_shards_free);   // released on every early exit
+    zkg_msm_shards *h = holder.get();
     h->n = n; h->shards.resize((size_t)ndev);
     std::vector<int> rc((size_t)ndev, ZKG_OK);
     std::vector<std::thread> th;
+    {
+    JoinAll join_guard{th};
     for (int i = 0; i < ndev; ++i) {
         zkg_msm_shards::Shard &sh = h->shards[(size_t)i];
         sh.device = devices[i]; sh.first = n * (size_t)i / (size_t)ndev; sh.n = n * (size_t)(i + 1) / (size_t)ndev - sh.first;
@@ -388,10 +392,16 @@ zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const 
                 (sh.n && !hip_ok(hipMemcpy(sh.bases.p, bases + 8 * sh.first, sh.n * 64, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__))) rc[(size_t)i] = ZKG_ERROR;
         });
     }
-    for (auto &t : th) t.join();
-    for (int r : rc) if (r) { zkg_msm_g1_shards_free(h); return nullptr; }
-    return h;
+    }
+    for (int r : rc) if (r) return nullptr;
+    return holder.release();
 }
+zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const int *devices, int ndev) {
+    try { return zkg_msm_g1_shards_upload_impl(bases, n, devices, ndev); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("zkg_msm_g1_shards_upload: ") + e.what()); return nullptr; }
+    catch (...) { zk::set_error("zkg_msm_g1_shards_upload: unexpected exception"); return nullptr; }
+}
+
 void zkg_msm_g1_shards_free(zkg_msm_shards *h) {
     if (!h) return;
     int cur = 0; (void)hipGetDevice(&cur);
@@ -401,7 +411,7 @@ void zkg_msm_g1_shards_free(zkg_msm_shards *h) {
 }
 size_t zkg_msm_g1_shards_count(const zkg_msm_shards *h, size_t *points) { if (points) *points = h ? h->n : 0; return h ? h->shards.size() : 0; }
 
-int zkg_msm_g1_multi(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
+static int zkg_msm_g1_multi_impl(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
     zkg_msm_shards *h = const_cast<zkg_msm_shards *>(h_);
     if (!h || !out_jac || (h->n && !scalars)) { set_error("zkg_msm_g1_multi: bad argument"); return ZKG_ERROR; }
     const size_t ns = h->shards.size();
@@ -415,17 +425,25 @@ int zkg_msm_g1_multi(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t
             msm_job_launch(sh.job, &set, 1, sh.scalars.as<uint32_t>(), sh.n, false) || msm_job_finish(sh.job, &part[i], nullptr)) rc[i] = ZKG_ERROR;
     };
     std::vector<std::thread> th;
-    for (size_t i = 1; i < ns; ++i) th.emplace_back(run, i);
-    int cur = 0; (void)hipGetDevice(&cur);
-    run(0);                                                                       // shard 0 on the calling thread
-    (void)hipSetDevice(cur);
-    for (auto &t : th) t.join();
+    {
+        JoinAll join_guard{th};
+        for (size_t i = 1; i < ns; ++i) th.emplace_back(run, i);
+        int cur = 0; (void)hipGetDevice(&cur);
+        run(0);                                                                   // shard 0 on the calling thread
+        (void)hipSetDevice(cur);
+    }
     for (int r : rc) if (r) return ZKG_ERROR;
     G1 acc = G1::inf();
     for (size_t i = 0; i < ns; ++i) { if (partials_jac) store_norm(partials_jac + 12 * i, part[i]); acc.add(part[i]); }
     store_norm(out_jac, acc);
     return ZKG_OK;
 }
+int zkg_msm_g1_multi(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
+    try { return zkg_msm_g1_multi_impl(h_, scalars, out_jac, partials_jac); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("zkg_msm_g1_multi: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { zk::set_error("zkg_msm_g1_multi: unexpected exception"); return ZKG_ERROR; }
+}
+
 
 void zkg_timing_reset(void) { g_dominant_timer.reset(); }
 float zkg_timing_dominant_ms(int *launches) { return g_dominant_timer.drain(launches); }

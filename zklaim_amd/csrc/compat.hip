@@ -99,7 +99,7 @@ void random_fr_mont(uint64_t out[4]) {
 
 extern "C" {
 
-int libsnark_trusted_setup(zklaim_ctx *ctx) {
+static int libsnark_trusted_setup_impl(zklaim_ctx *ctx) {
     if (!ctx) return ZKLAIM_ERROR;
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return ZKLAIM_ERROR;
@@ -125,8 +125,14 @@ int libsnark_trusted_setup(zklaim_ctx *ctx) {
     zkg_keypair_free(kp);
     return rc;
 }
+int libsnark_trusted_setup(zklaim_ctx *ctx) {
+    try { return libsnark_trusted_setup_impl(ctx); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("libsnark_trusted_setup: ") + e.what()); return ZKLAIM_ERROR; }
+    catch (...) { zk::set_error("libsnark_trusted_setup: unexpected exception"); return ZKLAIM_ERROR; }
+}
 
-int libsnark_prove(zklaim_ctx *ctx) {
+
+static int libsnark_prove_impl(zklaim_ctx *ctx) {
     if (!ctx || !ctx->pk || !ctx->pk_size) return ZKLAIM_ERROR;
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return ZKLAIM_ERROR;
@@ -176,14 +182,26 @@ int libsnark_prove(zklaim_ctx *ctx) {
     zkg_circuit_free(ck);
     return rc;
 }
+int libsnark_prove(zklaim_ctx *ctx) {
+    try { return libsnark_prove_impl(ctx); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("libsnark_prove: ") + e.what()); return ZKLAIM_ERROR; }
+    catch (...) { zk::set_error("libsnark_prove: unexpected exception"); return ZKLAIM_ERROR; }
+}
 
-int libsnark_verify(zklaim_ctx *ctx) {
+
+static int libsnark_verify_impl(zklaim_ctx *ctx) {
     if (!ctx || !ctx->vk || !ctx->proof) return 1;
     size_t n = zkg_zklaim_input_map(ctx, nullptr, 0);
     std::vector<uint64_t> input(4 * n + 4);
     zkg_zklaim_input_map(ctx, input.data(), n);                   // verify_proof: input = zklaim_input_map(ctx) (snark.cpp:58-62)
     return zkg_groth16_verify(ctx->vk, ctx->vk_size, input.data(), n, ctx->proof, ctx->proof_size) == 0 ? 0 : 1;
 }
+int libsnark_verify(zklaim_ctx *ctx) {
+    try { return libsnark_verify_impl(ctx); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("libsnark_verify: ") + e.what()); return 1; }
+    catch (...) { zk::set_error("libsnark_verify: unexpected exception"); return 1; }
+}
+
 
 // drops the resident keys cached by libsnark_prove (tests / long-running hosts)
 void zkg_compat_reset(void) {

@@ -340,7 +340,7 @@ using namespace zk;
 
 extern "C" {
 
-zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
+static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk) {
     if (!pk) { set_error("zkg_crs_upload: null pk"); return nullptr; }
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("zkg_crs_upload: no HIP device (call zkg_init)"); return nullptr; }
@@ -405,6 +405,12 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
     if (!ok) { zkg_crs_free(crs); return nullptr; }
     return crs;
 }
+zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
+    try { return zkg_crs_upload_impl(pk); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("zkg_crs_upload: ") + e.what()); return nullptr; }
+    catch (...) { zk::set_error("zkg_crs_upload: unexpected exception"); return nullptr; }
+}
+
 
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
@@ -418,7 +424,7 @@ void zkg_crs_free(zkg_crs *crs) {
 
 uint32_t zkg_crs_num_variables(const zkg_crs *crs) { return crs ? crs->n : 0; }
 
-int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
+static int zkg_qap_witness_h_impl(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
@@ -430,6 +436,12 @@ int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_
     memset(h_out + 4 * crs->m, 0, 32);                                      // coefficients_for_H[m] = 0
     return ZKG_OK;
 }
+int zkg_qap_witness_h(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
+    try { return zkg_qap_witness_h_impl(crs_, witness, h_out); }                      // nothing propagates through the C boundary
+    catch (const std::exception &e) { zk::set_error(std::string("zkg_qap_witness_h: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { zk::set_error("zkg_qap_witness_h: unexpected exception"); return ZKG_ERROR; }
+}
+
 
 // ---- one proof = prove_enqueue (everything the GPU does, queued without waiting) + prove_finish (host tails, assembly, bytes)
 static const bool g_dbg_timing = getenv("ZKG_DEBUG_TIMING") != nullptr, g_serial_msm = getenv("ZKG_SERIAL_MSM") != nullptr;
@@ -557,8 +569,8 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     return ZKG_OK;
 }
 
-int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64_t r_[4], const uint64_t s_[4], int check_satisfied,
-                      uint8_t *proof_out, size_t *proof_len) {
+static int groth16_prove_impl(const zkg_crs *crs_, const uint64_t *witness, const uint64_t r_[4], const uint64_t s_[4], int check_satisfied,
+                              uint8_t *proof_out, size_t *proof_len) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !witness)) { set_error("zkg_groth16_prove: bad argument"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(crs->mu);
@@ -571,8 +583,8 @@ int zkg_groth16_prove(const zkg_crs *crs_, const uint64_t *witness, const uint64
 // the same proof from a sparse description of the witness: tags[n] (0 = zero, 1 = one, 2 = listed) and `count` listed variables as
 // (index among the n variables, value as 4 Montgomery limbs).  What a witness generator that knows its bits hands over: the upload
 // shrinks ~30x (see k_expand_tags).  Identical proof bytes to zkg_groth16_prove on the expanded vector.
-int zkg_groth16_prove_sparse(const zkg_crs *crs_, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
-                             const uint64_t r_[4], const uint64_t s_[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len) {
+static int groth16_prove_sparse_impl(const zkg_crs *crs_, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
+                                     const uint64_t r_[4], const uint64_t s_[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !tags) || (count && (!full_index || !full_values)) || count > crs->n) {
         set_error("zkg_groth16_prove_sparse: bad argument"); return ZKG_ERROR;
@@ -582,6 +594,20 @@ int zkg_groth16_prove_sparse(const zkg_crs *crs_, const uint8_t *tags, const uin
     WitnessSrc W; W.tags = tags; W.idx = full_index; W.vals = full_values; W.count = count;
     if (prove_enqueue(crs, S, W, r_, s_, check_satisfied != 0)) { slot_drain(crs, S); return ZKG_ERROR; }
     return prove_finish(crs, S, proof_out, proof_len);
+}
+
+// helper threads and host containers are used below these two: nothing may propagate through the C boundary
+int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4], int check_satisfied,
+                      uint8_t *proof_out, size_t *proof_len) {
+    try { return groth16_prove_impl(crs, witness, r, s, check_satisfied, proof_out, proof_len); }
+    catch (const std::exception &e) { set_error(std::string("zkg_groth16_prove: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { set_error("zkg_groth16_prove: unexpected exception"); return ZKG_ERROR; }
+}
+int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
+                             const uint64_t r[4], const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len) {
+    try { return groth16_prove_sparse_impl(crs, tags, full_index, full_values, count, r, s, check_satisfied, proof_out, proof_len); }
+    catch (const std::exception &e) { set_error(std::string("zkg_groth16_prove_sparse: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { set_error("zkg_groth16_prove_sparse: unexpected exception"); return ZKG_ERROR; }
 }
 
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
