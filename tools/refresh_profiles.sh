@@ -14,6 +14,7 @@ echo "bench done" && tail -c 300 $OUT/r2_bench.json
 # headline MSM: per-kernel durations of the same command (no CPU legs, no extras)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o b -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || exit 1
 cp $OUT/kstats/b_kernel_stats.csv $OUT/r2_bench_kernel_stats.csv
+cp $OUT/bench_under_rocprof.json $OUT/r2_bench_under_rocprof.json
 python3 tools/kstats.py $OUT/r2_bench_kernel_stats.csv
 # NTT 2^20 alone (BASELINE configs[2])
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_ntt -o n -- python3 tools/ntt_profile.py 20 50 > $OUT/ntt_under_rocprof.log 2>&1 || exit 1
