@@ -76,6 +76,14 @@ def test_prove_from_pk_blob(zkg, oracle, case):
         pass
     with pytest.raises(zkg.ZkgError):
         zkg.Crs(blob=blob[: len(blob) // 2], m=case["m"])
+    # hostile counts (the blob comes from the issuer): every count is bounded by the bytes that follow it before anything is sized by
+    # it, so 2^61 A_query entries, a count just past the end, or 20 digits are refusals, not wrapped products or allocations
+    head = 34 + 34 + 66 + 34 + 66
+    nl = blob.index(b"\n", head)
+    assert int(blob[head:nl]) == case["num_variables"] + 1
+    for bogus in (b"2305843009213693952", b"%d" % (case["num_variables"] + 2), b"99999999999999999999", b"4294967296"):
+        with pytest.raises(zkg.ZkgError):
+            zkg.Crs(blob=blob[:head] + bogus + blob[nl:], m=case["m"])
 
 
 def test_pk_blob_zklaim_shaped(zkg, oracle):

@@ -92,3 +92,21 @@ def test_verify_golden_proofs(oracle, case):
     # swapping A and C (both G1) is a well-formed but invalid proof
     swapped = proof[100:134] + proof[34:100] + proof[0:34]
     assert zkg.groth16_verify(vk, x, swapped) == 1
+
+
+def test_hostile_counts_in_a_vk_blob_are_refused(oracle):
+    """counts inside a key blob are bounded by the bytes that follow them before anything is sized by them: a vk whose gamma_ABC
+    header claims 2^61 indices / values, or more values than the blob holds, is 'malformed' (2), never an allocation or a crash"""
+    keep = []
+    vk, x = build_vk(oracle, CASES[1], keep)
+    proof = bytes.fromhex(CASES[1]["proof_hex"])
+    head = 384 + 66 + 66 + 34
+    assert zkg.groth16_verify(vk, x, proof) == 0
+    l = CASES[1]["num_inputs"]
+    tail_idx = b"".join(b"%d\n" % i for i in range(l))
+    pts = vk[len(vk) - 34 * l:]
+    for dom, nidx, nval in ((1 << 61, 1 << 61, l), (l, l, 1 << 61), (l, l, l + 5), ((1 << 64) - 1, l, l), (10 ** 19, l, l)):
+        forged = vk[:head] + b"%d\n%d\n" % (dom, nidx) + tail_idx + b"%d\n" % nval + pts
+        assert zkg.groth16_verify(forged, x, proof) in (1, 2), (dom, nidx, nval)
+    forged = vk[:head] + b"%d\n%d\n" % (l, l) + tail_idx + b"%d\n" % l + pts[:-10]                 # truncated values
+    assert zkg.groth16_verify(forged, x, proof) == 2
