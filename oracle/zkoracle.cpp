@@ -712,7 +712,7 @@ int zko_qap_witness_h(const zkg_r1cs *cs, const u64 *w, u64 *h_out) {
 int zko_groth16_prove(const zkg_pk *pk, const u64 *w, const u64 r_[4], const u64 s_[4], int check_satisfied,
                       uint8_t *proof_out, size_t *proof_len, int chunks) {
     const zkg_r1cs &cs = pk->cs;
-    if (check_satisfied && !zko_r1cs_is_satisfied(&cs, w)) return ZKG_UNSATISFIED;
+    if (check_satisfied && !zko_r1cs_is_satisfied(&cs, w)) return 1;          // the reference's own return value at this gate (libsnark_wrapper.cpp:233-240)
     std::vector<Fr> H; size_t m;
     if (qap_witness_map(cs, w, H, m)) return 2;
     if (m != (pk->domain_size ? (size_t)pk->domain_size : ((size_t)1 << pk->log_m))) return 2;
