@@ -9,6 +9,7 @@
 // variables in the same call, so the structure never depends on the values.
 #pragma once
 #include <array>
+#include <initializer_list>
 #include <cstring>
 #include "r1cs_builder.hpp"
 
@@ -24,22 +25,28 @@ struct Bit {
     Bit operator!() const { Bit b = *this; if (is_const()) b.konst = 1 - konst; else b.neg = !neg; return b; }
     LC lc() const { if (is_const()) return LC::constant((uint64_t)konst); return neg ? LC::constant(1) - LC(v) : LC(v); }
     bool value(const Builder &pb) const { if (is_const()) return konst != 0; bool x = pb.is_nonzero(v); return neg ? !x : x; }
+    bool value(const uint8_t *tags) const { return is_const() ? konst != 0 : ((tags[v] != 0) != neg); }      // tags: Builder::tag_data()
 };
 
 inline Bit new_bit(Builder &pb, bool value) { Var v = pb.alloc(); pb.set_bit(v, value); return Bit::var(v); }
+// The witness-only pass (one per proof, on the seam's critical path) evaluates the same gates in the same order, but reads and writes
+// the one-byte tags directly instead of going through the builder for every bit: 27 K gates per payload.
+inline Bit new_bit_w(Builder &pb, bool value) { Var v = pb.alloc(); pb.tag_data()[v] = value; return Bit::var(v); }     // (alloc may move the storage: pointer taken after it)
 
 inline Bit bit_xor(Builder &pb, Bit a, Bit b) {
     if (a.is_const()) return a.konst ? !b : b;
     if (b.is_const()) return b.konst ? !a : a;
+    if (!pb.recording) { const uint8_t *tags = pb.tag_data(); return new_bit_w(pb, a.value(tags) != b.value(tags)); }
     Bit r = new_bit(pb, a.value(pb) != b.value(pb));
-    if (pb.recording) pb.enforce(a.lc() * 2, b.lc(), a.lc() + b.lc() - r.lc());                 // 2ab = a + b - r
+    pb.enforce(a.lc() * 2, b.lc(), a.lc() + b.lc() - r.lc());                                   // 2ab = a + b - r
     return r;
 }
 inline Bit bit_and(Builder &pb, Bit a, Bit b) {
     if (a.is_const()) return a.konst ? b : Bit::zero();
     if (b.is_const()) return b.konst ? a : Bit::zero();
+    if (!pb.recording) { const uint8_t *tags = pb.tag_data(); return new_bit_w(pb, a.value(tags) && b.value(tags)); }
     Bit r = new_bit(pb, a.value(pb) && b.value(pb));
-    if (pb.recording) pb.enforce(a.lc(), b.lc(), r.lc());
+    pb.enforce(a.lc(), b.lc(), r.lc());
     return r;
 }
 inline Bit bit_or(Builder &pb, Bit a, Bit b) { return !bit_and(pb, !a, !b); }
@@ -48,8 +55,9 @@ inline Bit bit_xor3(Builder &pb, Bit a, Bit b, Bit c) { return bit_xor(pb, bit_x
 inline Bit bit_choice(Builder &pb, Bit e, Bit f, Bit g) {
     if (e.is_const()) return e.konst ? f : g;
     if (f.is_const() && g.is_const()) { if (f.konst == g.konst) return f; return f.konst ? e : !e; }
+    if (!pb.recording) { const uint8_t *tags = pb.tag_data(); return new_bit_w(pb, e.value(tags) ? f.value(tags) : g.value(tags)); }
     Bit r = new_bit(pb, e.value(pb) ? f.value(pb) : g.value(pb));
-    if (pb.recording) pb.enforce(e.lc(), f.lc() - g.lc(), r.lc() - g.lc());                     // e (f - g) = r - g
+    pb.enforce(e.lc(), f.lc() - g.lc(), r.lc() - g.lc());                                       // e (f - g) = r - g
     return r;
 }
 inline Bit bit_majority(Builder &pb, Bit a, Bit b, Bit c) {
@@ -57,9 +65,10 @@ inline Bit bit_majority(Builder &pb, Bit a, Bit b, Bit c) {
     if (b.is_const()) return b.konst ? bit_or(pb, a, c) : bit_and(pb, a, c);
     if (c.is_const()) return c.konst ? bit_or(pb, a, b) : bit_and(pb, a, b);
     Bit t = bit_and(pb, a, b);
+    if (!pb.recording) { const uint8_t *tags = pb.tag_data(); return new_bit_w(pb, (int)a.value(tags) + (int)b.value(tags) + (int)c.value(tags) >= 2); }
     int s = (int)a.value(pb) + (int)b.value(pb) + (int)c.value(pb);
     Bit r = new_bit(pb, s >= 2);
-    if (pb.recording) pb.enforce(c.lc(), a.lc() + b.lc() - t.lc() * 2, r.lc() - t.lc());         // r = ab + c (a + b - 2ab)
+    pb.enforce(c.lc(), a.lc() + b.lc() - t.lc() * 2, r.lc() - t.lc());                           // r = ab + c (a + b - 2ab)
     return r;
 }
 
@@ -67,24 +76,75 @@ inline Bit bit_majority(Builder &pb, Bit a, Bit b, Bit c) {
 //      (libsnark_wrapper.cpp:65-74) produces for the bytes of a block)
 typedef std::array<Bit, 32> Word;
 inline Word word_const(uint32_t x) { Word w; for (int i = 0; i < 32; ++i) w[i] = ((x >> (31 - i)) & 1) ? Bit::one() : Bit::zero(); return w; }
-inline Word rotr(const Word &w, int n) { Word o; for (int i = 0; i < 32; ++i) o[i] = w[(i - n + 32) % 32]; return o; }
+inline Word rotr(const Word &w, int n) { Word o; for (int i = 0; i < 32; ++i) o[i] = w[(i - n) & 31]; return o; }
 inline Word shr(const Word &w, int n) { Word o; for (int i = 0; i < 32; ++i) o[i] = i >= n ? w[i - n] : Bit::zero(); return o; }
 inline LC word_lc(const Word &w) { LC l; for (int i = 0; i < 32; ++i) l = l + w[i].lc() * ((uint64_t)1 << (31 - i)); return l; }
-inline uint32_t word_value(const Builder &pb, const Word &w) { uint32_t x = 0; for (int i = 0; i < 32; ++i) x |= (uint32_t)w[i].value(pb) << (31 - i); return x; }
-inline Word word_xor3(Builder &pb, const Word &a, const Word &b, const Word &c) { Word o; for (int i = 0; i < 32; ++i) o[i] = bit_xor3(pb, a[i], b[i], c[i]); return o; }
+inline uint32_t word_value(const Builder &pb, const Word &w) { const uint8_t *tags = pb.tag_data(); uint32_t x = 0; for (int i = 0; i < 32; ++i) x |= (uint32_t)w[i].value(tags) << (31 - i); return x; }
+inline bool word_plain(const Word &w) { for (auto &b : w) if (b.is_const()) return false; return true; }                     // 32 variables, no constant
+// Witness-only word operations.  When every input bit is a variable the gates of a word allocate their outputs in a fixed pattern (two per
+// bit for a three-way xor and for a majority, one for a choice), so the word is evaluated on native 32-bit values and its outputs are
+// written as one block of tags — same variables, same order, same values as the gate-by-gate path, which the recording pass and any
+// word with a constant bit (shifted-in zeros, the IV, the padding) still take.
+inline Word word_xor3(Builder &pb, const Word &a, const Word &b, const Word &c) {
+    Word o;
+    if (!pb.recording && word_plain(a) && word_plain(b) && word_plain(c)) {
+        const uint32_t A = word_value(pb, a), B = word_value(pb, b), T = A ^ B, Rv = T ^ word_value(pb, c);
+        const Var f = pb.alloc_block(64);
+        uint8_t *tags = pb.tag_data();
+        for (int i = 0; i < 32; ++i) { tags[f + 2 * i] = (T >> (31 - i)) & 1; tags[f + 2 * i + 1] = (Rv >> (31 - i)) & 1; o[i] = Bit::var(f + 2 * i + 1); }
+        return o;
+    }
+    for (int i = 0; i < 32; ++i) o[i] = bit_xor3(pb, a[i], b[i], c[i]);
+    return o;
+}
+inline Word word_choice(Builder &pb, const Word &e, const Word &f, const Word &g) {
+    Word o;
+    if (!pb.recording && word_plain(e) && word_plain(f) && word_plain(g)) {
+        const uint32_t E = word_value(pb, e), Rv = (E & word_value(pb, f)) | (~E & word_value(pb, g));
+        const Var first = pb.alloc_block(32);
+        uint8_t *tags = pb.tag_data();
+        for (int i = 0; i < 32; ++i) { tags[first + i] = (Rv >> (31 - i)) & 1; o[i] = Bit::var(first + i); }
+        return o;
+    }
+    for (int i = 0; i < 32; ++i) o[i] = bit_choice(pb, e[i], f[i], g[i]);
+    return o;
+}
+inline Word word_majority(Builder &pb, const Word &a, const Word &b, const Word &c) {
+    Word o;
+    if (!pb.recording && word_plain(a) && word_plain(b) && word_plain(c)) {
+        const uint32_t A = word_value(pb, a), B = word_value(pb, b), C = word_value(pb, c), T = A & B, Rv = T | (C & (A ^ B));
+        const Var first = pb.alloc_block(64);                                   // per bit: t = a AND b, then the majority
+        uint8_t *tags = pb.tag_data();
+        for (int i = 0; i < 32; ++i) { tags[first + 2 * i] = (T >> (31 - i)) & 1; tags[first + 2 * i + 1] = (Rv >> (31 - i)) & 1; o[i] = Bit::var(first + 2 * i + 1); }
+        return o;
+    }
+    for (int i = 0; i < 32; ++i) o[i] = bit_majority(pb, a[i], b[i], c[i]);
+    return o;
+}
 
 // sum of words (+ constant) mod 2^32.  The low 32 result bits are fresh boolean variables, or `out` when given (variables
 // whose booleanity is enforced elsewhere); the carry bits are fresh and boolean-constrained here.
-inline Word add_mod32(Builder &pb, const std::vector<Word> &terms, uint32_t konst, const Var *out = nullptr) {
+inline Word add_mod32(Builder &pb, std::initializer_list<const Word *> terms, uint32_t konst, const Var *out = nullptr) {
     bool all_const = true;
-    for (auto &w : terms) for (auto &b : w) all_const = all_const && b.is_const();
+    for (const Word *w : terms) for (auto &b : *w) all_const = all_const && b.is_const();
     uint64_t sum = konst; LC s;
-    for (auto &w : terms) sum += word_value(pb, w);
+    for (const Word *w : terms) sum += word_value(pb, *w);
     if (all_const && !out) return word_const((uint32_t)sum);
     const bool rec = pb.recording;
-    if (rec) { s = LC::constant((uint64_t)konst); for (auto &w : terms) s = s + word_lc(w); }
+    if (rec) { s = LC::constant((uint64_t)konst); for (const Word *w : terms) s = s + word_lc(*w); }
     int extra = 0; while (((uint64_t)(terms.size() + 1) << 32) > ((uint64_t)1 << (32 + extra))) ++extra;   // enough carry bits for the worst case
     Word r; LC packed;
+    if (!rec) {                                                                // witness-only: result bits (unless given) and carries as one block of tags
+        const uint32_t nres = out ? 0 : 32;
+        const Var first = pb.alloc_block(nres + (uint32_t)extra);
+        uint8_t *tags = pb.tag_data();
+        for (int i = 0; i < 32; ++i) {
+            if (out) r[i] = Bit::var(out[i]);
+            else { tags[first + i] = (sum >> (31 - i)) & 1; r[i] = Bit::var(first + i); }
+        }
+        for (int j = 0; j < extra; ++j) tags[first + nres + j] = (sum >> (32 + j)) & 1;
+        return r;
+    }
     for (int i = 0; i < 32; ++i) {                                             // weight 2^(31-i)
         bool bv = (sum >> (31 - i)) & 1;
         if (out) { r[i] = Bit::var(out[i]); }
@@ -117,22 +177,22 @@ inline void sha256_compress_from_iv(Builder &pb, const std::vector<Bit> &block /
     for (int t = 16; t < 64; ++t) {
         Word s0 = word_xor3(pb, rotr(W[t - 15], 7), rotr(W[t - 15], 18), shr(W[t - 15], 3));
         Word s1 = word_xor3(pb, rotr(W[t - 2], 17), rotr(W[t - 2], 19), shr(W[t - 2], 10));
-        W[t] = add_mod32(pb, {W[t - 16], s0, W[t - 7], s1}, 0);
+        W[t] = add_mod32(pb, {&W[t - 16], &s0, &W[t - 7], &s1}, 0);
     }
     Word r[8];
     for (int j = 0; j < 8; ++j) r[j] = word_const(SHA256_IV[j]);
     for (int t = 0; t < 64; ++t) {
         const Word &a = r[0], &b = r[1], &c = r[2], &d = r[3], &e = r[4], &f = r[5], &g = r[6], &h = r[7];
         Word S1 = word_xor3(pb, rotr(e, 6), rotr(e, 11), rotr(e, 25));
-        Word ch; for (int i = 0; i < 32; ++i) ch[i] = bit_choice(pb, e[i], f[i], g[i]);
+        Word ch = word_choice(pb, e, f, g);
         Word S0 = word_xor3(pb, rotr(a, 2), rotr(a, 13), rotr(a, 22));
-        Word mj; for (int i = 0; i < 32; ++i) mj[i] = bit_majority(pb, a[i], b[i], c[i]);
-        Word new_e = add_mod32(pb, {d, h, S1, ch, W[t]}, SHA256_K[t]);
-        Word new_a = add_mod32(pb, {h, S1, ch, W[t], S0, mj}, SHA256_K[t]);
+        Word mj = word_majority(pb, a, b, c);
+        Word new_e = add_mod32(pb, {&d, &h, &S1, &ch, &W[t]}, SHA256_K[t]);
+        Word new_a = add_mod32(pb, {&h, &S1, &ch, &W[t], &S0, &mj}, SHA256_K[t]);
         for (int j = 7; j >= 1; --j) r[j] = r[j - 1];
         r[4] = new_e; r[0] = new_a;
     }
-    for (int j = 0; j < 8; ++j) add_mod32(pb, {r[j]}, SHA256_IV[j], &digest_out[32 * j]);
+    for (int j = 0; j < 8; ++j) add_mod32(pb, {&r[j]}, SHA256_IV[j], &digest_out[32 * j]);
 }
 
 // packing: 1 * sum_i 2^i bits[i] = packed      (libsnark packing_gadget; little-endian over the given order)
@@ -143,9 +203,11 @@ inline void enforce_packing(Builder &pb, const std::vector<Var> &bits, size_t lo
     pb.enforce(LC::constant(1), s, LC(packed));
 }
 inline void assign_packing(Builder &pb, const std::vector<Var> &bits, size_t lo, size_t hi, Var packed) {
-    Fr s = Fr::zero(), w = Fr::one();
-    for (size_t i = lo; i < hi; ++i) { if (pb.is_nonzero(bits[i])) s += w; w = w.dbl(); }
-    pb.set(packed, s);
+    // at most 253 bits (FieldT::capacity()): the integer is assembled in 32-bit limbs and converted to Montgomery form once
+    Fr s = Fr::zero();
+    const uint8_t *tags = pb.tag_data();
+    for (size_t i = lo; i < hi && i - lo < 256; ++i) if (tags[bits[i]]) s.v[(i - lo) >> 5] |= 1u << ((i - lo) & 31);
+    pb.set(packed, s.to_mont());
 }
 
 // comparison of two n-bit values (libsnark comparison_gadget semantics): less = [A < B], less_or_eq = [A <= B].
@@ -175,7 +237,8 @@ inline void comparison_witness(Builder &pb, const Comparison &c, size_t n, uint6
     if ((alpha >> 64) & 1) { Fr t = Fr::one(); for (int i = 0; i < 64; ++i) t = t.dbl(); packed += t; }
     pb.set(c.alpha_packed, packed);
     pb.set_bit(c.not_all_zeros, cnt != 0);
-    pb.set(c.inv, cnt ? Fr::from_u64(cnt).inverse() : Fr::zero());
+    static const std::array<Fr, 65> inv_table = [] { std::array<Fr, 65> t; t[0] = Fr::zero(); for (uint64_t i = 1; i <= 64; ++i) t[i] = Fr::from_u64(i).inverse(); return t; }();
+    pb.set(c.inv, cnt <= 64 ? inv_table[cnt] : Fr::from_u64(cnt).inverse());          // 1 / (number of set bits): one of 64 values for n <= 64
     bool leq = (alpha >> n) & 1;
     pb.set_bit(less_or_eq, leq);
     pb.set_bit(less, leq && cnt);

@@ -40,6 +40,7 @@ struct Builder {
     std::vector<std::pair<Var, Fr>> arena;
     uint32_t num_inputs = 0;
     bool recording = true;               // false: witness-only pass (the proving key already holds the constraint system)
+    bool bits_lazy = false;              // set by the owner before a witness-only pass: boolean variables carry their tag only until materialize_bits()
     // A view allocates from a pre-sized range [cursor, cursor_end) of its root's storage and reads / writes values there: the
     // per-payload sub-circuits of a witness-only pass are independent and run on separate threads through views.
     Builder *root = nullptr; uint32_t cursor = 0, cursor_end = 0, cursor_begin = 0; bool overrun = false;
@@ -62,9 +63,28 @@ struct Builder {
         }
         val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1);
     }
+    // n consecutive fresh variables, first index returned (values zero).  A view that cannot supply them falls back to alloc()'s overrun path.
+    Var alloc_block(uint32_t n) {
+        if (root) {
+            if (cursor + n <= cursor_end) { Var f = cursor; cursor += n; return f; }
+            Var f = alloc(); for (uint32_t i = 1; i < n; ++i) (void)alloc(); return f;
+        }
+        return (Var)extend(n);
+    }
     void set(Var v, const Fr &x) { Builder &r = root ? *root : *this; r.val[v] = x; r.nz[v] = x.is_zero() ? 0 : (x == Fr::one() ? 1 : 2); }
-    void set_bit(Var v, bool b) { Builder &r = root ? *root : *this; r.val[v] = b ? Fr::one() : Fr::zero(); r.nz[v] = b; }
+    // A boolean variable.  In a witness-only pass only its tag is written: the tags (one byte per variable) are what the prover's sparse
+    // upload and the gadgets read, and the 32-byte field value of a 0 / 1 variable is implied by it (materialize_bits() fills the values
+    // in for callers that ask for the dense vector) — 27 K variables per payload, 33 bytes each otherwise.
+    void set_bit(Var v, bool b) { Builder &r = root ? *root : *this; r.nz[v] = b; if (!r.bits_lazy) r.val[v] = b ? Fr::one() : Fr::zero(); }
+    void materialize_bits() {
+        if (!bits_lazy) return;
+        const Fr one = Fr::one(), zero = Fr::zero();
+        for (size_t v = 0; v < val.size(); ++v) if (nz[v] < 2) val[v] = nz[v] ? one : zero;
+        bits_lazy = false;
+    }
     bool is_nonzero(Var v) const { return (root ? root : this)->nz[v] != 0; }
+    uint8_t *tag_data() { return (root ? root : this)->nz.data(); }              // one byte per variable (see nz); stable while no variable is appended
+    const uint8_t *tag_data() const { return (root ? root : this)->nz.data(); }
     std::vector<Var> alloc_n(size_t n) {
         std::vector<Var> v(n);
         if (root) { for (auto &x : v) x = alloc(); return v; }
