@@ -101,9 +101,13 @@ struct Pool {
             if (r) drain(*r);
         }
     }
-    void run(int count, const std::function<void(int)> &f) {
+    void run(int count, const std::function<void(int)> &f, bool wait_for_pool) {
         if (count <= 1 || workers.empty()) { for (int i = 0; i < count; ++i) f(i); return; }
-        std::lock_guard<std::mutex> rl(run_mu);
+        // the pool runs one loop at a time; a caller that finds it busy (the seam's key-digest thread hashing 200 MB, say) does its own
+        // few tasks inline rather than queueing behind it — these loops sit on the latency path of a proof
+        std::unique_lock<std::mutex> rl(run_mu, std::defer_lock);
+        if (wait_for_pool) rl.lock();
+        else if (!rl.try_lock()) { for (int i = 0; i < count; ++i) f(i); return; }
         auto r = std::make_shared<Run>(); r->fn = f; r->n = count;
         { std::lock_guard<std::mutex> lk(mu); cur = r; ++epoch; }
         cv_work.notify_all();
@@ -113,7 +117,9 @@ struct Pool {
     }
 };
 }  // namespace
-void host_parallel_for(int n, const std::function<void(int)> &fn) { static Pool pool; pool.run(n, fn); }
+static Pool &host_pool() { static Pool pool; return pool; }
+void host_parallel_for(int n, const std::function<void(int)> &fn) { host_pool().run(n, fn, false); }
+void host_parallel_for_wait(int n, const std::function<void(int)> &fn) { host_pool().run(n, fn, true); }
 
 // ---- ABI point encodings -----------------------------------------------------------------------
 static void put(uint64_t *out, const Fq &a) { memcpy(out, a.v, 32); }

@@ -35,7 +35,10 @@ struct KernelTimer {
 extern KernelTimer g_dominant_timer;
 
 // small persistent host thread pool (the per-window tails of the MSMs are independent; see msm.hip host_combine)
+// host_parallel_for: a caller that finds the pool busy runs its tasks inline (short loops on a proof's latency path);
+// host_parallel_for_wait: queues behind the running loop (bulk work that must be parallel: hashing a 200 MB key blob)
 void host_parallel_for(int n, const std::function<void(int)> &fn);
+void host_parallel_for_wait(int n, const std::function<void(int)> &fn);
 
 // ---------------- NTT (ntt.hip) ----------------
 struct NttDomain {

@@ -72,7 +72,7 @@ Digest128 full_digest(const unsigned char *p, size_t n) {
     const size_t CHUNK = (size_t)1 << 18;
     const size_t nchunks = (n + CHUNK - 1) / CHUNK;
     std::vector<Digest128> part(nchunks);
-    host_parallel_for((int)nchunks, [&](int c) {
+    host_parallel_for_wait((int)nchunks, [&](int c) {
         const size_t lo = (size_t)c * CHUNK, hi = std::min(n, lo + CHUNK);
         uint64_t l[4] = {0x243F6A8885A308D3ull ^ (uint64_t)c, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};    // four independent lanes
         size_t i = lo;

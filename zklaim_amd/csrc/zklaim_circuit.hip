@@ -135,15 +135,13 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
                 refv[i][j] = pl.data_ref[j];
                 pb.set(data[i][j], Fr::from_u64(attr[i][j]));
             }
-        });
-        // the packings read those bits and write one variable each: independent of one another
-        host_parallel_for((int)n_inputs, [&](int c) { assign_packing(pb, input_as_bits, (size_t)c * FR_CAPACITY, std::min(input_bits, ((size_t)c + 1) * FR_CAPACITY), input_fe[c]); });
-        host_parallel_for((int)k, [&](int ii) {
-            const size_t i = (size_t)ii;
+            // the payload's own packings read the bits just set and write one variable each
             for (size_t c = 6 * i; c < 6 * (i + 1); ++c) assign_packing(pb, PL, c * 64, (c + 1) * 64, plvars[c]);
             for (size_t c = 8 * i; c < 8 * (i + 1); ++c) assign_packing(pb, REF, c * 64, (c + 1) * 64, refvals[c]);
             for (size_t c = 64 * i; c < 64 * (i + 1); ++c) assign_packing(pb, OPS, c * 8, (c + 1) * 8, opsvals[c]);
         });
+        // the public-input packings span payloads (253 bits each, assembled natively): too little work for another trip through the pool
+        for (size_t c = 0; c < n_inputs; ++c) assign_packing(pb, input_as_bits, c * FR_CAPACITY, std::min(input_bits, (c + 1) * FR_CAPACITY), input_fe[c]);
     }
 
     lap("allocation + public values");
