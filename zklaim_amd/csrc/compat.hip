@@ -85,7 +85,7 @@ Digest128 full_digest(const unsigned char *p, size_t n) {
     return d;
 }
 void random_fr_mont(uint64_t out[4]) {
-    std::random_device rd;
+    static thread_local std::random_device rd;               // opened once per thread, not once per scalar
     for (;;) {
         uint32_t v[8]; for (auto &x : v) x = rd();
         v[7] &= 0x3fffffffu;

@@ -87,11 +87,20 @@ inline bool word_plain(const Word &w) { for (auto &b : w) if (b.is_const()) retu
 // word with a constant bit (shifted-in zeros, the IV, the padding) still take.
 inline Word word_xor3(Builder &pb, const Word &a, const Word &b, const Word &c) {
     Word o;
-    if (!pb.recording && word_plain(a) && word_plain(b) && word_plain(c)) {
+    if (!pb.recording && word_plain(a) && word_plain(b)) {
+        // a, b variables; c variables or constants (the zeros a shift brings in): per bit t = a xor b is a fresh variable, and t xor c is
+        // another one unless c is constant there (then it is t or its negation)
         const uint32_t A = word_value(pb, a), B = word_value(pb, b), T = A ^ B, Rv = T ^ word_value(pb, c);
-        const Var f = pb.alloc_block(64);
+        uint32_t nvar_c = 0;
+        for (auto &x : c) nvar_c += !x.is_const();
+        Var pos = pb.alloc_block(32 + nvar_c);
         uint8_t *tags = pb.tag_data();
-        for (int i = 0; i < 32; ++i) { tags[f + 2 * i] = (T >> (31 - i)) & 1; tags[f + 2 * i + 1] = (Rv >> (31 - i)) & 1; o[i] = Bit::var(f + 2 * i + 1); }
+        for (int i = 0; i < 32; ++i) {
+            tags[pos] = (T >> (31 - i)) & 1;
+            const Var t = pos++;
+            if (c[i].is_const()) { o[i] = Bit::var(t); if (c[i].konst) o[i] = !o[i]; }
+            else { tags[pos] = (Rv >> (31 - i)) & 1; o[i] = Bit::var(pos++); }
+        }
         return o;
     }
     for (int i = 0; i < 32; ++i) o[i] = bit_xor3(pb, a[i], b[i], c[i]);
@@ -126,9 +135,15 @@ inline Word word_majority(Builder &pb, const Word &a, const Word &b, const Word 
 // whose booleanity is enforced elsewhere); the carry bits are fresh and boolean-constrained here.
 inline Word add_mod32(Builder &pb, std::initializer_list<const Word *> terms, uint32_t konst, const Var *out = nullptr) {
     bool all_const = true;
-    for (const Word *w : terms) for (auto &b : *w) all_const = all_const && b.is_const();
     uint64_t sum = konst; LC s;
-    for (const Word *w : terms) sum += word_value(pb, *w);
+    {   // value and constness of every term in one pass over its bits
+        const uint8_t *tags = pb.tag_data();
+        for (const Word *w : terms) {
+            uint32_t x = 0;
+            for (int i = 0; i < 32; ++i) { const Bit &b = (*w)[i]; all_const = all_const && b.is_const(); x |= (uint32_t)b.value(tags) << (31 - i); }
+            sum += x;
+        }
+    }
     if (all_const && !out) return word_const((uint32_t)sum);
     const bool rec = pb.recording;
     if (rec) { s = LC::constant((uint64_t)konst); for (const Word *w : terms) s = s + word_lc(*w); }
