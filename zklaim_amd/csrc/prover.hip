@@ -16,11 +16,13 @@
 #include "../../include/zkg.h"
 #include <algorithm>
 #include <chrono>
-#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <functional>
+#include <condition_variable>
+#include <thread>
 #include <vector>
 
 namespace zk {
@@ -33,6 +35,32 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 // scratch, a stream for the mat-vec / NTT pipeline, three MSM jobs (stream + workspace + pinned landing zone each) and the
 // events that order them.  One per key: keeping two proofs in flight (the host tail of proof i under the GPU work of proof
 // i+1) was built and measured in round 1 — slower, because one proof's concurrent MSMs already fill the chip.
+// One persistent helper thread per prover slot: it queues the witness streams' work while the calling thread queues the critical path, and
+// later computes one of the two variable-base products of the assembly.  (std::async spawned a thread for each: 30-50 us apiece on every
+// proof, and the occasional multi-millisecond outlier when the spawn was slow.)
+struct Helper {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::function<int()> task; bool has_task = false, done = true, stop = false; int result = 0;
+    void start() { th = std::thread([this] { loop(); }); }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || stop; });
+            if (stop) return;
+            std::function<int()> t = std::move(task); has_task = false;
+            lk.unlock();
+            int r = ZKG_ERROR;
+            try { r = t(); } catch (...) { r = ZKG_ERROR; }
+            lk.lock();
+            result = r; done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> f) { std::lock_guard<std::mutex> lk(mu); task = std::move(f); has_task = true; done = false; cv.notify_all(); }
+    int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); return result; }
+    void shutdown() { if (!th.joinable()) return; { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); th.join(); }
+};
+
 struct ProverSlot {
     zk::DevBuf z, aABC, flag, up_tags, up_idx, up_vals;    // up_*: staging of a sparse witness                   // [1 | w] and aA | aB | aC back to back (batched NTTs)
     zk::DevBuf ntt_scratch;                     // inter-pass scratch, 3 m elements
@@ -42,6 +70,7 @@ struct ProverSlot {
     zk::MsmJob *job_w1 = nullptr, *job_w2 = nullptr, *job_h = nullptr;
     zk::OnesSum ones_g1, ones_g2;               // flat sums of the bases whose witness element is one: (A, B_g1, L) and B_g2, on streams of their own
     hipStream_t stream_o = nullptr;
+    Helper helper;
     hipEvent_t ev[20]; bool ev_ok = false, ready = false;
     float stage_ms[8] = {0};
     // the proof in flight between prove_enqueue and prove_finish
@@ -319,10 +348,12 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
         for (auto &e : S.ev) if (hipEventCreate(&e) != hipSuccess) S.ev_ok = false;
         if (!S.ev_ok) { set_error("hipEventCreate failed"); ok = false; }
     }
+    if (ok) S.helper.start();
     S.ready = ok;
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 static void slot_destroy(ProverSlot &S) {
+    S.helper.shutdown();
     for (DevBuf *b : {&S.z, &S.aABC, &S.flag, &S.ntt_scratch, &S.up_tags, &S.up_idx, &S.up_vals, &S.wtags, &S.wlisted, &S.wcount}) b->release();
     msm_job_destroy(S.job_w1); msm_job_destroy(S.job_w2); msm_job_destroy(S.job_h);
     S.job_w1 = S.job_w2 = S.job_h = nullptr;
@@ -493,9 +524,8 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         }
         return ZKG_OK;
     };
-    std::future<int> witness_jobs;
     const bool helper = !g_serial_msm && g_witness_start == 0;                  // a later start event must have been recorded before it is waited for
-    if (helper) witness_jobs = std::async(std::launch::async, witness_fn);
+    if (helper) S.helper.submit(witness_fn);
     int rc = compute_h_transforms(crs, S);
     lap(S, "transforms enqueued");
     // H: uniformly random scalars, follows the transforms in stream order
@@ -507,7 +537,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
-    const int rc_w = helper ? witness_jobs.get() : witness_fn();          // (profiling aid: every job alone on the chip, one after the other)
+    const int rc_w = helper ? S.helper.wait() : witness_fn();          // (profiling aid: every job alone on the chip, one after the other)
     lap(S, "msm jobs enqueued");
     return rc == ZKG_OK ? rc_w : rc;
 }
@@ -540,12 +570,14 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     if (msm_job_finish(S.job_w1, W1, nullptr) || !hip_ok(hipStreamSynchronize(S.stream_o), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
     for (int i = 0; i < 3; ++i) W1[i].add(S.ones_g1.g1(i));                   // bucket method over the non-bit elements + flat sum over the ones
     // the two variable-base products s W_a and r W_b: the second one on a helper thread
-    auto rWb = std::async(std::launch::async, [&] { return W1[1].mul(rc, 8); });
+    G1 rWb;
+    S.helper.submit([&]() -> int { rWb = W1[1].mul(rc, 8); return ZKG_OK; });
     G1 gC = W1[0].mul(sc, 8);
     gA.add(W1[0]);
     size_t off = 0;
     off += ser_g1(proof_out + off, gA);
-    gC.add(rWb.get()); gC.add(c_fixed); gC.add(W1[2]);
+    (void)S.helper.wait();
+    gC.add(rWb); gC.add(c_fixed); gC.add(W1[2]);
     lap(S, "A serialised, s*Wa + r*Wb + L");
     if (msm_job_finish(S.job_w2, nullptr, &Bt2) || !hip_ok(hipEventSynchronize(S.ev[10]), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
     Bt2.add(S.ones_g2.g2pt(0));
