@@ -15,6 +15,39 @@
 
 namespace zk { namespace pairing {
 
+// ---- host-only field inversion by the binary extended Euclidean algorithm on 4 x 64-bit limbs.  Fp::inverse() is Fermat's x^(p-2)
+//      (380 products, 12 us on a host core), fine for a handful of conversions but the Miller loop below inverts once per step: 89
+//      inversions were a fifth of a verification.  Montgomery in, Montgomery out: the integer inverse of aR is a^-1 R^-1; one Montgomery
+//      product with R^3 turns it into a^-1 R.
+namespace hostinv {
+struct U256 { uint64_t w[4]; };
+inline bool is_one(const U256 &a) { return a.w[0] == 1 && !(a.w[1] | a.w[2] | a.w[3]); }
+inline bool geq(const U256 &a, const U256 &b) { for (int i = 3; i >= 0; --i) if (a.w[i] != b.w[i]) return a.w[i] > b.w[i]; return true; }
+inline void sub(U256 &a, const U256 &b) { unsigned __int128 br = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)a.w[i] - b.w[i] - (uint64_t)br; a.w[i] = (uint64_t)d; br = (d >> 64) & 1; } }
+inline void add(U256 &a, const U256 &b) { unsigned __int128 c = 0; for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a.w[i] + b.w[i]; a.w[i] = (uint64_t)c; c >>= 64; } }
+inline void shr1(U256 &a) { for (int i = 0; i < 3; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 63); a.w[3] >>= 1; }
+inline void halve_mod(U256 &x, const U256 &p) { if (x.w[0] & 1) add(x, p); shr1(x); }              // x / 2 mod p  (x < p < 2^254: no overflow)
+inline void sub_mod(U256 &x, const U256 &y, const U256 &p) { if (geq(x, y)) sub(x, y); else { add(x, p); sub(x, y); } }
+}  // namespace hostinv
+inline Fq fq_inverse_host(const Fq &x) {
+    using namespace hostinv;
+    U256 u, v, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}}, p;
+    for (int i = 0; i < 4; ++i) { u.w[i] = x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32); p.w[i] = FqParams::P[2 * i] | ((uint64_t)FqParams::P[2 * i + 1] << 32); }
+    if (!(u.w[0] | u.w[1] | u.w[2] | u.w[3])) return Fq::zero();
+    v = p;
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u.w[0] & 1)) { shr1(u); halve_mod(x1, p); }
+        while (!(v.w[0] & 1)) { shr1(v); halve_mod(x2, p); }
+        if (geq(u, v)) { sub(u, v); sub_mod(x1, x2, p); } else { sub(v, u); sub_mod(x2, x1, p); }
+    }
+    const U256 &r = is_one(u) ? x1 : x2;                                        // (aR)^-1 as an integer
+    Fq out;
+    for (int i = 0; i < 4; ++i) { out.v[2 * i] = (uint32_t)r.w[i]; out.v[2 * i + 1] = (uint32_t)(r.w[i] >> 32); }
+    static const Fq R3 = Fq::r2() * Fq::r2();                                   // the limbs of R^3 mod q
+    return out * R3;
+}
+inline Fq2 fq2_inverse_host(const Fq2 &a) { Fq d = fq_inverse_host(a.c0.sqr() + a.c1.sqr()); return {a.c0 * d, (a.c1 * d).neg()}; }
+
 inline Fq2 fq2(uint64_t a, uint64_t b) { return {Fq::from_u64(a), Fq::from_u64(b)}; }
 inline Fq2 xi() { return fq2(9, 1); }
 inline Fq2 mul_xi(const Fq2 &a) { return a * xi(); }
@@ -40,7 +73,7 @@ struct Fq6 {
     Fq6 mul_by_v() const { return {mul_xi(c2), c0, c1}; }
     Fq6 inverse() const {
         Fq2 t0 = c0.sqr() - mul_xi(c1 * c2), t1 = mul_xi(c2.sqr()) - c0 * c1, t2 = c1.sqr() - c0 * c2;
-        Fq2 d = (c0 * t0 + mul_xi(c2 * t1) + mul_xi(c1 * t2)).inverse();
+        Fq2 d = fq2_inverse_host(c0 * t0 + mul_xi(c2 * t1) + mul_xi(c1 * t2));
         return {t0 * d, t1 * d, t2 * d};
     }
 };
@@ -136,7 +169,7 @@ inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
     auto invert_all = [&]() {                                // den[j] <- 1/den[j]
         Fq2 run = Fq2::one();
         for (int j = 0; j < n; ++j) { pre[j] = run; run = run * den[j]; }
-        Fq2 inv = run.inverse();
+        Fq2 inv = fq2_inverse_host(run);
         for (int j = n - 1; j >= 0; --j) { Fq2 d = inv * pre[j]; inv = inv * den[j]; den[j] = d; }
     };
     auto apply = [&](int j, const Fq2 &lambda, const Fq2 &x_other) {       // multiply the line in, move T_j along it
