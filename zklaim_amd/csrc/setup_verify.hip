@@ -284,7 +284,8 @@ int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]
 }
 
 // test hook: 0 when (1) x -> x^(q^k) by coefficient maps equals square-and-multiply by q^k (k = 1, 2, 3) and (2) the last chunk of the
-// final exponentiation equals square-and-multiply by the integer `e` (nlimbs x u32, little-endian); bit flags otherwise
+// final exponentiation equals square-and-multiply by the integer `e` (nlimbs x u32, little-endian) and (3) the projective and the
+// affine Miller loops give the same reduced pairing products; bit flags otherwise
 int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
     uint32_t k3[8] = {3}, k5[8] = {5};
     G1Affine P = G1::from_affine(g1_generator()).mul(k3, 8).to_affine();
@@ -296,6 +297,13 @@ int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
     Fq12 g = pairing::final_exponentiation_first_chunk(f);
     if (!(g.conjugate() * g == Fq12::one())) bad |= 8;                        // in the cyclotomic subgroup: g^(q^6) = g^-1
     if (e && nlimbs > 0 && !(pairing::final_exponentiation_last_chunk(g) == g.pow(e, nlimbs))) bad |= 16;
+    {   // the inversion-free lock-step Miller loop against the affine one of the definition: equal after the final exponentiation
+        uint32_t k[6][8] = {{7}, {11}, {0x9e3779b9u, 0x7f4a7c15u, 0xf39cc060u, 5}, {13}, {0xdeadbeefu, 0x12345678u, 0xcafef00du, 0x0badc0deu, 0x31415926u, 0x27182818u, 0x16180339u, 0x1}, {17}};
+        G1Affine Ps[3]; G2Affine Qs[3];
+        for (int j = 0; j < 3; ++j) { Ps[j] = G1::from_affine(g1_generator()).mul(k[j], 8).to_affine(); Qs[j] = G2::from_affine(g2_generator()).mul(k[3 + j], 8).to_affine(); }
+        for (int n = 1; n <= 3; ++n)
+            if (!(pairing::final_exponentiation(pairing::multi_miller_loop(Ps, Qs, n)) == pairing::final_exponentiation(pairing::multi_miller_loop_affine(Ps, Qs, n)))) bad |= 32;
+    }
     return bad;
 }
 
