@@ -201,3 +201,66 @@ def test_prove_witness_split_edge_cases(zkg, oracle, shape):
     rc_s, proof_s = crs.prove_sparse(tags, idx, w[idx], rs[0], rs[1])
     assert rc_s == 0 and proof_s == proof, shape
     crs.free()
+
+
+def test_concurrent_callers_get_the_serial_proofs(zkg, oracle):
+    """Re-entrancy of the boundary (SURVEY §8(b) threading: the reference seam is not re-entrant, this one is).  Two resident keys of
+    different domain sizes, four host threads proving on them at once (two per key: callers of one key queue on its slot, the two
+    keys' pipelines really overlap on the GPU), MSM and NTT calls (host-pointer entry points, same sizes) from two more threads in between.  Every proof must be the byte
+    string the same call gives alone; the oracle pins one of them."""
+    import threading
+    from zklaim_amd import synth
+    keep = []
+    jobs = []
+    for log_m, seed in ((10, 3), (13, 4)):
+        n, l, A, B, C, w = synth.zklaim_shaped(log_m, num_inputs=5, seed=seed)
+        ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+        crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0xC0 + seed))
+        crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, log_m, keep))
+        rs = [random_fr_canonical(2, 0xD0 + 16 * seed + i) for i in range(6)]
+        alone = [crs.prove(w, r[0], r[1]) for r in rs]
+        assert all(rc == 0 for rc, _ in alone)
+        if log_m == 10:
+            rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0][0], rs[0][1])
+            assert rc_o == 0 and proof_o == alone[0][1]
+        jobs.append((crs, w, rs, [p for _, p in alone]))
+    from gpu_util import dev_bases_g1
+    _, bases, _ = dev_bases_g1(zkg, 3000, 77)
+    scalars = random_fr_canonical(3000, 78)
+    msm_alone = zkg.msm_g1(bases, scalars)
+    vec = random_fr_canonical(1 << 12, 79)
+    ntt_alone = zkg.ntt(vec)
+    errors = []
+
+    def prover(job, order):
+        crs, w, rs, expect = job
+        try:
+            for rep in range(4):
+                for i in order:
+                    rc, proof = crs.prove(w, rs[i][0], rs[i][1])
+                    if rc != 0 or proof != expect[i]:
+                        errors.append(("prove", i, rc))
+        except Exception as e:                                   # noqa: BLE001 — a failure on a worker thread must fail the test
+            errors.append(("exception", repr(e)))
+
+    def other():
+        try:
+            for _ in range(8):
+                if not np.array_equal(zkg.msm_g1(bases, scalars), msm_alone):
+                    errors.append(("msm",))
+                if not np.array_equal(zkg.ntt(vec), ntt_alone):
+                    errors.append(("ntt",))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("exception", repr(e)))
+
+    threads = [threading.Thread(target=prover, args=(jobs[0], range(6))), threading.Thread(target=prover, args=(jobs[0], range(5, -1, -1))),
+               threading.Thread(target=prover, args=(jobs[1], range(6))), threading.Thread(target=prover, args=(jobs[1], range(5, -1, -1))),
+               threading.Thread(target=other), threading.Thread(target=other)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:5]
+    for crs, *_ in jobs:
+        crs.free()

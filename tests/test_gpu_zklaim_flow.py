@@ -136,3 +136,46 @@ def test_c_caller_of_the_multi_gpu_entry_points(zkg, tmp_path):
     out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr[-500:])
     assert out.returncode == 0 and "ok" in out.stdout
+
+
+def test_seam_is_reentrant(zkg):
+    """The reference seam is single-caller (it closes fd 1, mutates libff globals and re-runs init_public_params per call,
+    libsnark_wrapper.cpp:197-212); this one takes callers from several threads: two credentials with their own keys, each proved and
+    verified repeatedly from its own thread while a third thread verifies a finished proof of the first.  Return codes only, like the
+    reference's own tests — proofs draw fresh r, s."""
+    import threading
+    ctxs = []
+    for k in (1, 2):
+        pls = [payload(["less_or_eq", "not_eq", "noop", "noop", "noop"], [40 + i, 9, 0, 0, 0], [40 + i, 8, i, 2, 3], 500 + 10 * k + i) for i in range(k)]
+        ctx, keep = run_flow(zkg, pls)
+        assert zkg.libsnark_verify(ctx) == 0
+        ctxs.append((ctx, keep))
+    # a finished, separate copy for the verifying thread (its proof is not overwritten by the provers)
+    pls = [payload(["less_or_eq", "not_eq", "noop", "noop", "noop"], [40, 9, 0, 0, 0], [40, 8, 0, 2, 3], 510)]
+    vctx, vkeep = run_flow(zkg, pls)
+    errors = []
+
+    def prove_verify(ctx):
+        try:
+            for _ in range(6):
+                if zkg.libsnark_prove(ctx) != 0 or zkg.libsnark_verify(ctx) != 0:
+                    errors.append("prove/verify")
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    def verify_only():
+        try:
+            for _ in range(12):
+                if zkg.libsnark_verify(vctx) != 0:
+                    errors.append("verify")
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=prove_verify, args=(c,)) for c, _ in ctxs] + [threading.Thread(target=verify_only)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:5]
+    zkg.lib().zkg_compat_reset()

@@ -226,9 +226,13 @@ int zkg_ntt_dev(void *d_a, unsigned logN, int inverse, int coset, void *stream) 
     if (!d) return ZKG_ERROR;
     return ntt_run(d, (Fr *)d_a, inverse, coset, s);
 }
+// The host-pointer transforms run on the null stream with the domain's shared inter-pass scratch: callers on several threads take turns
+// (device-pointer callers pass their own stream and get a scratch vector per stream, NttDomain::scratch_for).
+static std::mutex g_host_ntt_mu;
 int zkg_ntt(uint64_t *a, unsigned logN, int inverse, int coset) {
     REQUIRE_INIT();
     if (!a || logN > 28) { set_error("zkg_ntt: bad argument"); return ZKG_ERROR; }
+    std::lock_guard<std::mutex> lk(g_host_ntt_mu);
     size_t bytes = ((size_t)1 << logN) * 32;
     DevBuf buf;
     if (buf.reserve(bytes)) return ZKG_ERROR;
@@ -266,6 +270,7 @@ int zkg_ntt_domain_dev(void *d_a, size_t m, int inverse, int coset, void *stream
 int zkg_ntt_domain(uint64_t *a, size_t m, int inverse, int coset) {
     REQUIRE_INIT();
     if (!a || m < 2) { set_error("zkg_ntt_domain: bad argument"); return ZKG_ERROR; }
+    std::lock_guard<std::mutex> lk(g_host_ntt_mu);
     size_t bytes = m * 32;
     DevBuf buf;
     if (buf.reserve(bytes)) return ZKG_ERROR;
