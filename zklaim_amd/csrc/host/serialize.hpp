@@ -3,6 +3,8 @@
 // /root/reference/zklaim/libsnark_wrapper.cpp:126,142,150,165,173,189).  G1 = '0'|'1' X '0'|'1' (34 B), G2 66 B.
 #pragma once
 #include <cstring>
+#include <memory>
+#include <utility>
 #include <vector>
 #include "../curve.hip.hpp"
 #include "pairing.hpp"
@@ -76,8 +78,15 @@ inline void get_fq12(const uint8_t *p, pairing::Fq12 &g) {
     for (int i = 0; i < 6; ++i) { memcpy(c[i]->c0.v, p + 64 * i, 32); memcpy(c[i]->c1.v, p + 64 * i + 32, 32); }
 }
 
+// byte buffer whose resize() leaves new bytes uninitialised: the key writer sizes runs of hundreds of MB and fills them on the host pool
+template <class T> struct UninitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef UninitAlloc<U> other; };
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }             // default-init: no zero fill for bytes
+};
+typedef std::vector<uint8_t, UninitAlloc<uint8_t>> Bytes;
 struct Writer {
-    std::vector<uint8_t> buf;
+    Bytes buf;
     void dec(size_t v) {                                     // ASCII decimal + '\n' (millions of these in a pk: no snprintf)
         char t[24]; int n = 0;
         do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);

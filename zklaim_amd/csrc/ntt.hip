@@ -261,6 +261,13 @@ static int batch_invert(std::vector<Fr> &den) {
     for (int r : rc) if (r) return ZKG_ERROR;
     return ZKG_OK;
 }
+// f(lo, hi) over [0, n) in chunks on the host pool (a key generator's loops over the domain: independent per index once a chunk has
+// recomputed its starting power)
+template <class Fn> static void chunked(size_t n, Fn f) {
+    const int chunks = (int)std::min<size_t>(64, (n + 8191) / 8192);
+    if (chunks <= 1) { f((size_t)0, n); return; }
+    host_parallel_for(chunks, [&](int c) { f(n * (size_t)c / chunks, n * (size_t)(c + 1) / chunks); });
+}
 int domain_lagrange(const DomainShape &d, const Fr &t, std::vector<Fr> &u, Fr &Zt) {
     const size_t m = d.m;
     u.assign(m, Fr::zero());
@@ -268,21 +275,32 @@ int domain_lagrange(const DomainShape &d, const Fr &t, std::vector<Fr> &u, Fr &Z
     if (!d.step) {
         Fr omega = fr_root_of_unity_pow2(d.log_m), wi = Fr::one(), mf = Fr::from_u64(m);
         Zt = t.pow_u64(m) - Fr::one();
-        for (size_t i = 0; i < m; ++i) { u[i] = Zt * wi; den[i] = mf * (t - wi); wi = wi * omega; }
+        (void)wi;
+        chunked(m, [&](size_t lo, size_t hi) {                                             // each chunk restarts the running power at omega^lo
+            Fr w = omega.pow_u64(lo);
+            for (size_t i = lo; i < hi; ++i) { u[i] = Zt * w; den[i] = mf * (t - w); w = w * omega; }
+        });
     } else {
         const size_t big = d.big, small = d.small;
         Fr omega = fr_root_of_unity_pow2(d.log_m), wb = omega.sqr(), ws = fr_root_of_unity_pow2(ceil_log2(small));
         Fr omega_s = omega.pow_u64(small), Zb = t.pow_u64(big) - Fr::one(), L0 = t.pow_u64(small) - omega_s;
         Zt = Zb * L0;
         Fr wbs = wb.pow_u64(small), wi = Fr::one(), elt = Fr::one(), bf = Fr::from_u64(big), num = Zb * L0;
-        for (size_t i = 0; i < big; ++i) { u[i] = num * wi; den[i] = bf * (t - wi) * (elt - omega_s); wi = wi * wb; elt = elt * wbs; }
+        (void)wi; (void)elt;
+        chunked(big, [&](size_t lo, size_t hi) {
+            Fr w = wb.pow_u64(lo), e = wbs.pow_u64(lo);
+            for (size_t i = lo; i < hi; ++i) { u[i] = num * w; den[i] = bf * (t - w) * (e - omega_s); w = w * wb; e = e * wbs; }
+        });
         Fr tp = t * omega.inverse(), Zs = tp.pow_u64(small) - Fr::one(), sf = Fr::from_u64(small);
         Fr L1num = Zb * Zs, L1den = omega.pow_u64(big) - Fr::one();
-        wi = Fr::one();
-        for (size_t i = 0; i < small; ++i) { u[big + i] = L1num * wi; den[big + i] = L1den * sf * (tp - wi); wi = wi * ws; }
+        const Fr L1s = L1den * sf;
+        chunked(small, [&](size_t lo, size_t hi) {
+            Fr w = ws.pow_u64(lo);
+            for (size_t i = lo; i < hi; ++i) { u[big + i] = L1num * w; den[big + i] = L1s * (tp - w); w = w * ws; }
+        });
     }
     if (batch_invert(den)) { set_error("domain_lagrange: t is a domain point"); return ZKG_ERROR; }
-    for (size_t i = 0; i < m; ++i) u[i] = u[i] * den[i];
+    chunked(m, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) u[i] = u[i] * den[i]; });
     return ZKG_OK;
 }
 

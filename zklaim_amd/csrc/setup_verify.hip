@@ -28,7 +28,7 @@ struct zkg_keypair {
     // the (possibly swapped) constraint system stored in the pk
     std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
     uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0; bool swapped = false;
-    std::vector<uint8_t> pk_blob; std::mutex blob_mu;            // serialised once, on first request
+    ser::Bytes pk_blob; std::mutex blob_mu;            // serialised once, on first request
     G1Affine alpha_g1, beta_g1, delta_g1; G2Affine beta_g2, delta_g2, gamma_g2;
     std::vector<G1Affine> A_query, B_g1, H_query, L_query, IC;
     std::vector<G2Affine> B_g2;
@@ -126,16 +126,31 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     for (size_t i = 0; i <= l; ++i) At[i] = u[C + i];
     std::vector<Fr> *dst[3] = {&At, &Bt, &Ct};
     host_parallel_for(3, [&](int k) {                                       // the three matrices accumulate into separate vectors
+        const Fr one = Fr::one(), minus_one = Fr::one().neg();               // a gadget circuit's coefficients are mostly +-1: no product needed
         for (size_t i = 0; i < C; ++i)
-            for (uint32_t e = kp->rp[k][i]; e < kp->rp[k][i + 1]; ++e) { Fr c; memcpy(c.v, &kp->val[k][4 * (size_t)e], 32); (*dst[k])[kp->col[k][e]] += u[i] * c; }
+            for (uint32_t e = kp->rp[k][i]; e < kp->rp[k][i + 1]; ++e) {
+                Fr c; memcpy(c.v, &kp->val[k][4 * (size_t)e], 32);
+                Fr &acc = (*dst[k])[kp->col[k][e]];
+                if (c == one) acc += u[i]; else if (c == minus_one) acc -= u[i]; else acc += u[i] * c;
+            }
     });
     Fr dinv = delta.inverse(), ginv = gamma.inverse();
     std::vector<Fr> Hs(m - 1), Ls(n - l), ICs(l + 1);
-    { Fr ti = Fr::one(), zd = Zt * dinv; for (size_t i = 0; i + 1 < m; ++i) { Hs[i] = ti * zd; ti = ti * t; } }
-    for (size_t i = 0; i <= n; ++i) {
-        Fr abc = beta * At[i] + alpha * Bt[i] + Ct[i];
-        if (i <= l) ICs[i] = abc * ginv; else Ls[i - l - 1] = abc * dinv;
+    auto chunked = [&](size_t count, const std::function<void(size_t, size_t)> &f) {           // [0, count) in chunks on the host pool
+        const int chunks = (int)std::min<size_t>(64, (count + 8191) / 8192);
+        if (chunks <= 1) { f(0, count); return; }
+        host_parallel_for(chunks, [&](int c) { f(count * (size_t)c / chunks, count * (size_t)(c + 1) / chunks); });
+    };
+    {
+        const Fr zd = Zt * dinv;
+        chunked(m - 1, [&](size_t lo, size_t hi) { Fr ti = t.pow_u64(lo) * zd; for (size_t i = lo; i < hi; ++i) { Hs[i] = ti; ti = ti * t; } });   // t^i Z(t) / delta
     }
+    chunked(n + 1, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            Fr abc = beta * At[i] + alpha * Bt[i] + Ct[i];
+            if (i <= l) ICs[i] = abc * ginv; else Ls[i - l - 1] = abc * dinv;
+        }
+    });
     lap("qap evaluation + scalars");
     // ---- scalars -> points (GPU fixed-base batches)
     G1Affine g1 = g1_generator(); G2Affine g2 = g2_generator();
@@ -169,7 +184,7 @@ int zkg_keypair_swapped(const zkg_keypair *kp) { return kp && kp->swapped ? 1 : 
 
 // operator<<(r1cs_gg_ppzksnark_proving_key), layout in codec.hip.  Built once per keypair (callers ask for the size first, then for
 // the bytes); the fixed-size point records — 2.2 M of them at 20 payloads — are serialised on the host pool.
-static void build_pk_blob(const zkg_keypair *kp, std::vector<uint8_t> &buf) {
+static void build_pk_blob(const zkg_keypair *kp, ser::Bytes &buf) {
     ser::Writer w;
     std::vector<size_t> idx;
     for (size_t i = 0; i < kp->B_g2.size(); ++i) if (!kp->B_g2[i].is_inf() || !kp->B_g1[i].is_inf()) idx.push_back(i);
@@ -193,11 +208,28 @@ static void build_pk_blob(const zkg_keypair *kp, std::vector<uint8_t> &buf) {
     w.dec(kp->H_query.size()); records(kp->H_query.size(), 34, [&](size_t i, uint8_t *o) { ser::put_g1(o, kp->H_query[i]); });
     w.dec(kp->L_query.size()); records(kp->L_query.size(), 34, [&](size_t i, uint8_t *o) { ser::put_g1(o, kp->L_query[i]); });
     w.dec(kp->l); w.dec(kp->n - kp->l); w.dec(kp->C);
-    for (uint32_t c = 0; c < kp->C; ++c)
-        for (int k = 0; k < 3; ++k) {
-            w.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
-            for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { w.dec(kp->col[k][e]); w.raw(&kp->val[k][4 * (size_t)e], 32); }
-        }
+    {   // the constraint system: variable-length records (decimal counts and indices), so each chunk of rows is written to a buffer of its
+        // own on the pool and the buffers are then copied into place, also in parallel
+        const int chunks = (int)std::min<size_t>(64, ((size_t)kp->C + 4095) / 4096);
+        std::vector<ser::Writer> part(std::max(chunks, 1));
+        auto rows = [&](int ch) {
+            ser::Writer &pw = part[ch];
+            const uint32_t lo = (uint32_t)((size_t)kp->C * ch / std::max(chunks, 1)), hi = (uint32_t)((size_t)kp->C * (ch + 1) / std::max(chunks, 1));
+            size_t terms = 0;
+            for (int k = 0; k < 3; ++k) terms += kp->rp[k][hi] - kp->rp[k][lo];
+            pw.buf.reserve(terms * 40 + (size_t)(hi - lo) * 8 + 64);
+            for (uint32_t c = lo; c < hi; ++c)
+                for (int k = 0; k < 3; ++k) {
+                    pw.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
+                    for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { pw.dec(kp->col[k][e]); pw.raw(&kp->val[k][4 * (size_t)e], 32); }
+                }
+        };
+        if (chunks <= 1) rows(0); else host_parallel_for(chunks, rows);
+        std::vector<size_t> at(part.size() + 1, w.buf.size());
+        for (size_t i = 0; i < part.size(); ++i) at[i + 1] = at[i] + part[i].buf.size();
+        w.buf.resize(at.back());
+        host_parallel_for((int)part.size(), [&](int i) { if (!part[i].buf.empty()) memcpy(w.buf.data() + at[i], part[i].buf.data(), part[i].buf.size()); });
+    }
     buf.swap(w.buf);
 }
 size_t zkg_keypair_pk_blob(const zkg_keypair *kp_, uint8_t *out, size_t cap) {
@@ -205,7 +237,10 @@ size_t zkg_keypair_pk_blob(const zkg_keypair *kp_, uint8_t *out, size_t cap) {
     if (!kp) return 0;
     std::lock_guard<std::mutex> lk(kp->blob_mu);
     if (kp->pk_blob.empty()) build_pk_blob(kp, kp->pk_blob);
-    if (out && cap >= kp->pk_blob.size()) memcpy(out, kp->pk_blob.data(), kp->pk_blob.size());
+    if (out && cap >= kp->pk_blob.size()) {                                   // hundreds of MB into fresh pages: copy in parallel pieces
+        const size_t len = kp->pk_blob.size(); const int chunks = (int)std::min<size_t>(32, (len >> 22) + 1);
+        host_parallel_for(chunks, [&](int c) { size_t lo = len * (size_t)c / chunks, hi = len * (size_t)(c + 1) / chunks; memcpy(out + lo, kp->pk_blob.data() + lo, hi - lo); });
+    }
     return kp->pk_blob.size();
 }
 
