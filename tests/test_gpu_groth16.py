@@ -203,6 +203,42 @@ def test_prove_witness_split_edge_cases(zkg, oracle, shape):
     crs.free()
 
 
+def test_witness_tables_grow_with_the_witnesses_seen(zkg, oracle):
+    """The witness queries' window tables cover only the elements some proof has sent through the bucket method (subset tables,
+    prover.hip subset_extend).  One resident key, a sequence of witnesses whose non-bit positions differ: bits only (no table yet),
+    a first set of non-bit positions, a disjoint second set, their union, a witness with the public input and the first / last
+    variables non-bit (the L table holds infinity for the constant and the public inputs), and the first one again.  Every proof's
+    bytes against the oracle; blob-loaded key as well (queries decompressed on the device)."""
+    rng = np.random.default_rng(29)
+    n = 2500
+
+    def witness(nonbit_positions):
+        vals = [int(x) for x in rng.integers(0, 2, n)]
+        for p_ in nonbit_positions:
+            vals[p_] = int.from_bytes(rng.bytes(31), "little") % (R - 2) + 2
+        return vals
+
+    first = list(range(100, 400, 3)); second = list(range(1000, 1900, 7))
+    shapes = [[], first, second, first + second, [0, 1, n - 1], first]
+    n_, l, A, B, C, _ = _trivial_system([0] * n)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x71))
+    opk = oracle.make_pk(ocs, crs_arrays)
+    m = crs_arrays["m"]
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, (m - 1).bit_length(), keep, domain_size=m))
+    crs_blob = zkg.Crs(blob=oracle.pk_write_blob(opk), m=m)
+    for j, shape in enumerate(shapes):
+        w = arr(witness(shape), R)
+        rs = random_fr_canonical(2, 0x72 + j)
+        rc_o, proof_o = oracle.groth16_prove(opk, w, rs[0], rs[1])
+        assert rc_o == 0
+        for c in (crs, crs_blob):
+            rc, proof = c.prove(w, rs[0], rs[1])
+            assert rc == 0 and proof == proof_o, (j, c is crs_blob)
+    crs.free(); crs_blob.free()
+
+
 def test_concurrent_callers_get_the_serial_proofs(zkg, oracle):
     """Re-entrancy of the boundary (SURVEY §8(b) threading: the reference seam is not re-entrant, this one is).  Two resident keys of
     different domain sizes, four host threads proving on them at once (two per key: callers of one key queue on its slot, the two

@@ -18,7 +18,13 @@
 //   linear_combination             : #terms '\n' , (index '\n' coeff(32 B))*
 #include "common.hpp"
 #include "../../include/zkg.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace zk {
@@ -113,92 +119,125 @@ struct Reader {
     const uint8_t *take_records(size_t n, size_t record_bytes) { return take(n * record_bytes); }       // n came from count(record_bytes): no overflow
 };
 
+// n compressed records (stride bytes apart, the point at offset off) -> n affine points in d_out (device).  d_rec is staging for the records.
 template <class A, class K>
-static int decompress(K kernel, const uint8_t *host_rec, size_t stride, size_t off, size_t n, std::vector<uint64_t> &out, size_t limbs, DevBuf &d_rec, DevBuf &d_out, DevBuf &d_flag) {
-    out.assign(n * limbs, 0);
+static int decompress_dev(K kernel, const uint8_t *host_rec, size_t stride, size_t off, size_t n, A *d_out, DevBuf &d_rec, DevBuf &d_flag) {
     if (!n) return ZKG_OK;
-    if (d_rec.reserve(n * stride) || d_out.reserve(n * sizeof(A)) || d_flag.reserve(4)) return ZKG_ERROR;
+    if (d_rec.reserve(n * stride) || d_flag.reserve(4)) return ZKG_ERROR;
     ZK_HIP(hipMemcpy(d_rec.p, host_rec, n * stride, hipMemcpyHostToDevice));
-    ZK_HIP(hipMemset(d_flag.p, 0, 4));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_rec.as<uint8_t>(), stride, off, n, d_out.as<A>(), d_flag.as<uint32_t>());
-    uint32_t flag = 0;
-    ZK_HIP(hipMemcpy(&flag, d_flag.p, 4, hipMemcpyDeviceToHost));
-    if (flag) { set_error("pk blob: a compressed point is not on the curve"); return ZKG_ERROR; }
-    ZK_HIP(hipMemcpy(out.data(), d_out.p, n * sizeof(A), hipMemcpyDeviceToHost));
-    return ZKG_OK;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_rec.as<uint8_t>(), stride, off, n, d_out, d_flag.as<uint32_t>());
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
 
 }  // namespace zk
 
 using namespace zk;
+zkg_crs *crs_upload_device_queries(const zkg_pk *pk, const std::function<bool()> &constraint_system_ready);   // prover.hip
+
+// The constraint system section of a pk blob -> CSR arrays.  Runs on a thread of its own while the GPU decompresses the points and builds the
+// H table: the section is a serial walk (decimal counts and indices between 32-byte coefficients), 70 ms at 20 payloads.
+struct ParsedSystem { std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3]; std::string error; bool ok = false; };
+static void parse_constraint_system(Reader rd, size_t ncons, size_t n_elements, ParsedSystem &out) {
+    try {
+        const size_t bound = (size_t)(rd.end - rd.p) / 34;                  // a term takes at least 34 bytes: no more than this many in total
+        for (int m = 0; m < 3; ++m) { out.rp[m].reserve(ncons + 1); out.rp[m].push_back(0); out.col[m].reserve(bound / 2); out.val[m].reserve(bound * 2); }
+        for (size_t c = 0; c < ncons; ++c)
+            for (int m = 0; m < 3; ++m) {
+                size_t nt = rd.count(34);                                   // a term: index digits, newline, 32-byte coefficient
+                for (size_t t = 0; t < nt && rd.ok; ++t) {
+                    size_t index = rd.decimal(); const uint8_t *coeff = rd.take(32);
+                    if (!rd.ok || index >= n_elements) { out.error = "pk blob: bad linear term"; return; }
+                    out.col[m].push_back((uint32_t)index);
+                    uint64_t l4[4]; memcpy(l4, coeff, 32); out.val[m].insert(out.val[m].end(), l4, l4 + 4);
+                }
+                if (!rd.ok) { out.error = "pk blob: truncated constraint"; return; }
+                out.rp[m].push_back((uint32_t)out.col[m].size());
+            }
+        out.ok = true;
+    } catch (const std::exception &e) { out.error = std::string("pk blob: ") + e.what(); }
+}
 
 static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     if (!blob || len < 34 * 3 + 66 * 2) { set_error("zkg_crs_upload_blob: blob too short"); return nullptr; }
     Reader rd{(const uint8_t *)blob, (const uint8_t *)blob + len};
-    DevBuf d_rec, d_out, d_flag;
-    auto fail = [&](const char *msg) -> zkg_crs * { if (msg) set_error(msg); d_rec.release(); d_out.release(); d_flag.release(); return nullptr; };
-    // fixed head: alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg key blob] %-26s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
+    // ---- pass 1 (host, pointer arithmetic and the sparse vector's index list): where every section lies
     const uint8_t *alpha = rd.take(34), *beta1 = rd.take(34), *beta2 = rd.take(66), *delta1 = rd.take(34), *delta2 = rd.take(66);
-    if (!rd.ok) return fail("pk blob: truncated head");
-    std::vector<uint64_t> small1, small2, tmp;
-    uint8_t head1[3 * 34], head2[2 * 66];
-    memcpy(head1, alpha, 34); memcpy(head1 + 34, beta1, 34); memcpy(head1 + 68, delta1, 34);
-    memcpy(head2, beta2, 66); memcpy(head2 + 66, delta2, 66);
-    if (decompress<G1Affine>(k_decompress_g1, head1, 34, 0, 3, small1, 8, d_rec, d_out, d_flag) ||
-        decompress<G2Affine>(k_decompress_g2, head2, 66, 0, 2, small2, 16, d_rec, d_out, d_flag)) return fail(nullptr);
-    // A_query
+    if (!rd.ok) { set_error("pk blob: truncated head"); return nullptr; }
     size_t nA = rd.count(34); const uint8_t *recA = rd.take_records(nA, 34);
-    if (!rd.ok || nA == 0) return fail("pk blob: bad A_query");
-    std::vector<uint64_t> A_query, H_query, L_query, Bv_g2, Bv_g1;
-    if (decompress<G1Affine>(k_decompress_g1, recA, 34, 0, nA, A_query, 8, d_rec, d_out, d_flag)) return fail(nullptr);
+    if (!rd.ok || nA == 0) { set_error("pk blob: bad A_query"); return nullptr; }
     // B_query (sparse knowledge commitments: G2 then G1 per value)
     size_t domain = rd.count(0), nidx = rd.count(2);                      // an index is at least one digit and a newline
-    if (!rd.ok || domain != nA || nidx > domain) return fail("pk blob: bad B_query header");
-    std::vector<size_t> idx(nidx);
-    for (size_t i = 0; i < nidx; ++i) { idx[i] = rd.decimal(); if (!rd.ok || idx[i] >= domain) return fail("pk blob: bad B_query index"); }
+    if (!rd.ok || domain != nA || nidx > domain) { set_error("pk blob: bad B_query header"); return nullptr; }
+    std::vector<uint32_t> idx(nidx);
+    for (size_t i = 0; i < nidx; ++i) { size_t v = rd.decimal(); if (!rd.ok || v >= domain) { set_error("pk blob: bad B_query index"); return nullptr; } idx[i] = (uint32_t)v; }
     size_t nval = rd.count(100); const uint8_t *recB = rd.take_records(nval, 100);
-    if (!rd.ok || nval != nidx) return fail("pk blob: bad B_query values");
-    if (decompress<G2Affine>(k_decompress_g2, recB, 100, 0, nval, Bv_g2, 16, d_rec, d_out, d_flag) ||
-        decompress<G1Affine>(k_decompress_g1, recB, 100, 66, nval, Bv_g1, 8, d_rec, d_out, d_flag)) return fail(nullptr);
-    std::vector<uint64_t> B_g1(domain * 8, 0), B_g2(domain * 16, 0);                    // dense, absent = infinity
-    for (size_t i = 0; i < nidx; ++i) { memcpy(&B_g1[idx[i] * 8], &Bv_g1[i * 8], 64); memcpy(&B_g2[idx[i] * 16], &Bv_g2[i * 16], 128); }
-    // H_query, L_query
+    if (!rd.ok || nval != nidx) { set_error("pk blob: bad B_query values"); return nullptr; }
     size_t nH = rd.count(34); const uint8_t *recH = rd.take_records(nH, 34);
     size_t nL = rd.ok ? rd.count(34) : 0; const uint8_t *recL = rd.take_records(nL, 34);
-    if (!rd.ok) return fail("pk blob: bad H/L query");
-    if (decompress<G1Affine>(k_decompress_g1, recH, 34, 0, nH, H_query, 8, d_rec, d_out, d_flag) ||
-        decompress<G1Affine>(k_decompress_g1, recL, 34, 0, nL, L_query, 8, d_rec, d_out, d_flag)) return fail(nullptr);
-    // constraint system
+    if (!rd.ok) { set_error("pk blob: bad H/L query"); return nullptr; }
     size_t primary = rd.count(0), auxiliary = rd.count(0), ncons = rd.count(6);       // a constraint is at least three "0\n" term counts
-    if (!rd.ok || primary + auxiliary + 1 != nA || nL != auxiliary) return fail("pk blob: constraint system sizes disagree with the queries");
-    std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3];
-    for (int m = 0; m < 3; ++m) { rp[m].reserve(ncons + 1); rp[m].push_back(0); }
-    for (size_t c = 0; c < ncons; ++c)
-        for (int m = 0; m < 3; ++m) {
-            size_t nt = rd.count(34);                                       // a term: index digits, newline, 32-byte coefficient
-            for (size_t t = 0; t < nt && rd.ok; ++t) {
-                size_t index = rd.decimal(); const uint8_t *coeff = rd.take(32);
-                if (!rd.ok || index >= nA) return fail("pk blob: bad linear term");
-                col[m].push_back((uint32_t)index);
-                size_t at = val[m].size(); val[m].resize(at + 4); memcpy(&val[m][at], coeff, 32);
-            }
-            if (!rd.ok) return fail("pk blob: truncated constraint");
-            rp[m].push_back((uint32_t)col[m].size());
-        }
-    d_rec.release(); d_out.release(); d_flag.release();
+    if (!rd.ok || primary + auxiliary + 1 != nA || nL != auxiliary) { set_error("pk blob: constraint system sizes disagree with the queries"); return nullptr; }
     size_t m_dom = nH + 1;
     DomainShape shape;                                     // the domain size is not stored in the blob: H_query has m - 1 entries
     if (!domain_shape_of(m_dom, shape)) { set_error("pk blob: H_query length + 1 is neither a power of two nor a step_radix2 size 2^a + 2^b"); return nullptr; }
+    // ---- the constraint system on its own thread ...
+    ParsedSystem cs;
+    std::thread parser(parse_constraint_system, rd, ncons, nA, std::ref(cs));
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_guard{parser};       // on every return path, also an exception's
+    // ---- ... while the GPU decompresses the points (one lane per point) straight into the buffers the resident key is built from
+    DevBuf d_rec, d_flag, d_small, dA, dB1, dB2, dBv1, dBv2, dH, dL, d_idx;
+    auto fail = [&](const char *msg) -> zkg_crs * {
+        if (msg) set_error(msg);
+        for (DevBuf *b : {&d_rec, &d_flag, &d_small, &dA, &dB1, &dB2, &dBv1, &dBv2, &dH, &dL, &d_idx}) b->release();
+        return nullptr;
+    };
+    if (d_flag.reserve(4) || d_small.reserve(3 * 64 + 2 * 128) || dA.reserve(nA * 64) || dB1.reserve(domain * 64) || dB2.reserve(domain * 128) || dBv1.reserve(nval * 64 + 16) ||
+        dBv2.reserve(nval * 128 + 16) || dH.reserve(nH * 64 + 16) || dL.reserve(nL * 64 + 16) || d_idx.reserve(nidx * 4 + 16)) return fail(nullptr);
+    if (!hip_ok(hipMemset(d_flag.p, 0, 4), "memset", __FILE__, __LINE__) || !hip_ok(hipMemset(dB1.p, 0, domain * 64), "memset", __FILE__, __LINE__) ||
+        !hip_ok(hipMemset(dB2.p, 0, domain * 128), "memset", __FILE__, __LINE__)) return fail(nullptr);             // dense B: absent = infinity = zero bytes
+    uint8_t head1[3 * 34], head2[2 * 66];
+    memcpy(head1, alpha, 34); memcpy(head1 + 34, beta1, 34); memcpy(head1 + 68, delta1, 34);
+    memcpy(head2, beta2, 66); memcpy(head2 + 66, delta2, 66);
+    G1Affine *small1_dev = d_small.as<G1Affine>(); G2Affine *small2_dev = reinterpret_cast<G2Affine *>(small1_dev + 3);
+    if (decompress_dev<G1Affine>(k_decompress_g1, head1, 34, 0, 3, small1_dev, d_rec, d_flag) ||
+        decompress_dev<G2Affine>(k_decompress_g2, head2, 66, 0, 2, small2_dev, d_rec, d_flag) ||
+        decompress_dev<G1Affine>(k_decompress_g1, recA, 34, 0, nA, dA.as<G1Affine>(), d_rec, d_flag) ||
+        decompress_dev<G2Affine>(k_decompress_g2, recB, 100, 0, nval, dBv2.as<G2Affine>(), d_rec, d_flag) ||
+        decompress_dev<G1Affine>(k_decompress_g1, recB, 100, 66, nval, dBv1.as<G1Affine>(), d_rec, d_flag)) return fail(nullptr);
+    if (nidx) {
+        if (!hip_ok(hipMemcpy(d_idx.p, idx.data(), nidx * 4, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__) ||
+            scatter_points_g1(dBv1.as<G1Affine>(), d_idx.as<uint32_t>(), nidx, dB1.as<G1Affine>(), nullptr) ||
+            scatter_points_g2(dBv2.as<G2Affine>(), d_idx.as<uint32_t>(), nidx, dB2.as<G2Affine>(), nullptr)) return fail(nullptr);
+    }
+    if (decompress_dev<G1Affine>(k_decompress_g1, recH, 34, 0, nH, dH.as<G1Affine>(), d_rec, d_flag) ||
+        decompress_dev<G1Affine>(k_decompress_g1, recL, 34, 0, nL, dL.as<G1Affine>(), d_rec, d_flag)) return fail(nullptr);
+    uint32_t flag = 0; uint64_t small[3 * 8 + 2 * 16];
+    if (!hip_ok(hipMemcpy(&flag, d_flag.p, 4, hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__) ||
+        !hip_ok(hipMemcpy(small, d_small.p, sizeof(small), hipMemcpyDeviceToHost), "D2H", __FILE__, __LINE__)) return fail(nullptr);
+    if (flag) return fail("pk blob: a compressed point is not on the curve");
+    lap("points decompressed (GPU)");
     zkg_pk pk; memset(&pk, 0, sizeof(pk));
     pk.cs.num_variables = (uint32_t)(nA - 1); pk.cs.num_inputs = (uint32_t)primary; pk.cs.num_constraints = (uint32_t)ncons;
-    pk.cs.a_rowptr = rp[0].data(); pk.cs.a_col = col[0].data(); pk.cs.a_val = val[0].data();
-    pk.cs.b_rowptr = rp[1].data(); pk.cs.b_col = col[1].data(); pk.cs.b_val = val[1].data();
-    pk.cs.c_rowptr = rp[2].data(); pk.cs.c_col = col[2].data(); pk.cs.c_val = val[2].data();
     pk.log_m = shape.log_m; pk.domain_size = (uint32_t)shape.m;
-    pk.alpha_g1 = small1.data(); pk.beta_g1 = small1.data() + 8; pk.delta_g1 = small1.data() + 16;
-    pk.beta_g2 = small2.data(); pk.delta_g2 = small2.data() + 16;
-    pk.A_query = A_query.data(); pk.B_g1 = B_g1.data(); pk.B_g2 = B_g2.data(); pk.H_query = H_query.data(); pk.L_query = L_query.data();
-    return zkg_crs_upload(&pk);
+    pk.alpha_g1 = small; pk.beta_g1 = small + 8; pk.delta_g1 = small + 16;
+    pk.beta_g2 = small + 24; pk.delta_g2 = small + 40;
+    pk.A_query = dA.as<uint64_t>(); pk.B_g1 = dB1.as<uint64_t>(); pk.B_g2 = dB2.as<uint64_t>(); pk.H_query = dH.as<uint64_t>(); pk.L_query = dL.as<uint64_t>();   // DEVICE pointers
+    auto system_ready = [&]() -> bool {
+        parser.join();
+        lap("constraint system parsed");
+        if (!cs.ok) { set_error(cs.error.empty() ? "pk blob: bad constraint system" : cs.error.c_str()); return false; }
+        pk.cs.a_rowptr = cs.rp[0].data(); pk.cs.a_col = cs.col[0].data(); pk.cs.a_val = cs.val[0].data();
+        pk.cs.b_rowptr = cs.rp[1].data(); pk.cs.b_col = cs.col[1].data(); pk.cs.b_val = cs.val[1].data();
+        pk.cs.c_rowptr = cs.rp[2].data(); pk.cs.c_col = cs.col[2].data(); pk.cs.c_val = cs.val[2].data();
+        return true;
+    };
+    zkg_crs *crs = crs_upload_device_queries(&pk, system_ready);
+    lap("resident key built");
+    (void)fail(nullptr);                                                        // releases the staging buffers (no message)
+    return crs;
 }
 
 // Nothing may propagate through the C boundary: allocation failures on hostile sizes end up here as an error return.

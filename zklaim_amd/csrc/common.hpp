@@ -97,7 +97,9 @@ static constexpr int MSM_MAX_SETS = 4;                      // base sets sharing
 // one base set of a launch.  level_stride > 0: a per-window table (window_table_build_*): level w of the table, at p + w * level_stride
 // elements, holds 2^(c w) P_i, so every window shares one bucket set and the host has no doublings left.  index_sub: entry i of the
 // scalars stands for element i - index_sub of the set (the L query starts behind the constant and the public inputs); smaller i: no base.
-struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; };
+// remap (optional, device): element i of the scalars stands for entry remap[i] of the set — a table that holds only a subset of the key's
+// elements (the prover's witness tables cover the non-bit variables only).
+struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; const uint32_t *remap = nullptr; };
 struct WindowTable { DevBuf buf; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); n = 0; } };
 int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s);
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s);
@@ -113,7 +115,16 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2);   // out_g1[k]: k-th G1 set of the launch, out_g2[k]: k-th G2 set
 // the multi_exp_with_mixed_addition split of a witness z = [1 | w] (n1 elements, Montgomery): tags (0 zero, 1 one, 2 other), the
 // indices of the others and their count; and the flat sum of the bases tagged one (result lands in pinned host memory)
-int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s);
+// d_count: two words, [0] the number of listed elements, [1] set to 1 when a listed element has no entry in d_subset_pos (optional: position of
+// every element in the subset the witness tables were built for, SUBSET_NONE = absent)
+static constexpr uint32_t SUBSET_NONE = 0xffffffffu;
+int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s, const uint32_t *d_subset_pos = nullptr);
+// out[j] = idx[j] >= index_sub ? src[idx[j] - index_sub] : infinity   (level 0 of a subset table)
+int gather_points_g1(const G1Affine *d_src, const uint32_t *d_idx, size_t count, uint32_t index_sub, G1Affine *d_out, hipStream_t s);
+int gather_points_g2(const G2Affine *d_src, const uint32_t *d_idx, size_t count, uint32_t index_sub, G2Affine *d_out, hipStream_t s);
+// out[idx[j]] = src[j] (a sparse vector's values into their dense places; out must be zero-filled = all infinity)
+int scatter_points_g1(const G1Affine *d_src, const uint32_t *d_idx, size_t count, G1Affine *d_out, hipStream_t s);
+int scatter_points_g2(const G2Affine *d_src, const uint32_t *d_idx, size_t count, G2Affine *d_out, hipStream_t s);
 struct OnesSum {                                            // results: nsets points (G1 or G2, XYZZ) back to back in pinned host memory
     DevBuf partials; void *host = nullptr; bool g2 = false; int nsets = 0; void release();
     const G1 &g1(int i) const { return reinterpret_cast<const G1 *>(host)[i]; }

@@ -80,11 +80,12 @@ struct MsmGeom { uint32_t c, W, B, Wt, w0, ws; };
 // own accumulators, heavy lists and results laid out `set` strides apart (SetLayout), all walking the same sorted digit list.
 struct SetLayout { size_t buckets, items, heavy, partials, folded, red_out; };     // elements per set in each per-set array
 template <class F> struct BaseView {
-    const Affine<F> *p; size_t level_stride; const uint32_t *gather; uint32_t index_sub, B;
+    const Affine<F> *p; size_t level_stride; const uint32_t *gather; uint32_t index_sub, B; const uint32_t *remap;
     template <bool PLAIN = false> ZK_D Affine<F> load(uint32_t e, size_t gb) const {
         if constexpr (PLAIN) return p[e >> 1];            // a plain base set: nothing but the gather (the 2^20-point multi_exp's inner loop)
         uint32_t i = e >> 1;
         if (gather) i = gather[i];
+        if (remap) i = remap[i];                          // a subset table: position of element i in it
         if (i < index_sub) return Affine<F>::inf();
         return p[(level_stride ? (gb / B) * level_stride : 0) + (i - index_sub)];
     }
@@ -633,17 +634,39 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_bucket_fold(const XYZZ<F> *buc
     if (t < FB && b < B) out[b] = sh[t].normalized();
 }
 
-// level j+1 of a window table from level j: out_i = 2^c in_i (c doublings in XYZZ, one inversion back to affine)
-template <class F>
-__global__ __launch_bounds__(256) void k_table_level(const Affine<F> *in, Affine<F> *out, size_t n, uint32_t c) {
+// levels j+1 .. j+K of a window table from level j: level j+l = 2^(c l) * level j.  One lane walks a point through its K x c doublings in
+// XYZZ and normalises the K results with ONE inversion (Montgomery's trick over their ZZZ): a level per launch spent 80 % of its
+// time in the 380-product Fermat inversion of each point.  out points at level j+1; levels are n entries apart.
+template <class F, int K>
+__global__ __launch_bounds__(256) void k_table_levels(const Affine<F> *in, Affine<F> *out, size_t n, uint32_t c, int levels) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> a = in[i];
-    if (a.is_inf()) { out[i] = a; return; }
+    if (a.is_inf()) { for (int l = 0; l < levels; ++l) out[(size_t)l * n + i] = a; return; }
+    F x[K], y[K], zz[K], zzz[K];
     XYZZ<F> p = XYZZ<F>::dbl_affine_inl(a);
-    for (uint32_t k = 1; k < c; ++k) p = p.dbl();
-    XYZZ<F> fin = p;                       // to_affine() is out of line: only this copy has its address taken
-    out[i] = fin.to_affine().normalized();
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+        if (l < levels) {
+            for (uint32_t k = (l == 0 ? 1u : 0u); k < c; ++k) p = p.dbl();
+            x[l] = p.x; y[l] = p.y; zz[l] = p.zz; zzz[l] = p.zzz;
+        } else { x[l] = F::zero(); y[l] = F::zero(); zz[l] = F::zero(); zzz[l] = F::zero(); }
+    }
+    // (a point of a prime-order group never doubles to infinity; a hostile key's small-order G2 point can: ZZZ = 0 is skipped and restored)
+    F pre[K], run = F::one();
+#pragma unroll
+    for (int l = 0; l < K; ++l) { pre[l] = run; if (!zzz[l].is_zero()) run = run * zzz[l]; }
+    F inv = run.inverse();
+#pragma unroll
+    for (int l = K - 1; l >= 0; --l) {
+        if (l >= levels) continue;
+        if (zzz[l].is_zero()) { out[(size_t)l * n + i] = Affine<F>::inf(); continue; }
+        F zi = inv * pre[l];                                                    // 1 / ZZZ_l
+        inv = inv * zzz[l];
+        F t = zi * zz[l];                                                       // ZZ / ZZZ = 1 / Z
+        F zi2 = t.sqr();                                                        // 1 / ZZ
+        out[(size_t)l * n + i] = Affine<F>{x[l] * zi2, y[l] * zi}.normalized();
+    }
 }
 
 // ---- witness split (libff multi_exp_with_mixed_addition, reached from snark.cpp:126 for the A / B / L queries): a scalar that is 0 is
@@ -651,7 +674,7 @@ __global__ __launch_bounds__(256) void k_table_level(const Affine<F> *in, Affine
 //      of z = [1 | w] (0 zero, 1 one, 2 other) and lists the indices of the others; k_ones_sum adds the bases tagged 1 (a flat sum: lanes
 //      stride over the tags, LDS tree per workgroup, k_sum_partials finishes); the listed ones go through the digit sort as a gathered
 //      subset.  Both parts are exact group sums, so their total is the same point the reference's loop produces.
-__global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_t *tags, uint32_t *listed, uint32_t *count) {
+__global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_t *tags, uint32_t *listed, uint32_t *count, const uint32_t *subset_pos) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t tag = 0;
     if (i < n1) {
@@ -668,7 +691,22 @@ __global__ __launch_bounds__(256) void k_classify(const Fr *z, size_t n1, uint8_
     uint32_t base = 0;
     if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(count, (uint32_t)__popcll(mask));
     base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-    if (tag == 2) listed[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint32_t)i;
+    if (tag == 2) {
+        listed[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint32_t)i;
+        if (subset_pos && subset_pos[i] == SUBSET_NONE) count[1] = 1;        // the witness tables do not cover this element (yet)
+    }
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_gather_points(const Affine<F> *src, const uint32_t *idx, size_t count, uint32_t index_sub, Affine<F> *out) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t i = idx[j];
+    out[j] = i >= index_sub ? src[i - index_sub] : Affine<F>::inf();
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_scatter_points(const Affine<F> *src, const uint32_t *idx, size_t count, Affine<F> *out) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) out[idx[j]] = src[j];
 }
 template <class F>
 __global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const uint8_t *tags, size_t n1, XYZZ<F> *partials) {
@@ -757,14 +795,14 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     ViewSet<F> views;
     for (unsigned i = 0; i < (unsigned)MSM_MAX_SETS; ++i) {
         const MsmBases &b = sets[i < ns ? i : 0];
-        views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), b.level_stride, d_gather, b.index_sub, g.B};
+        views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), b.level_stride, d_gather, b.index_sub, g.B, b.remap};
     }
     // `order` lists the buckets by descending length, the empty ones last.  A table launch folds through the bucket lengths and never reads
     // an empty bucket, so its accumulation covers at most one lane per entry: a witness' ~10^5 entries over 2^19 buckets would otherwise
     // dispatch 8 K wavefronts that find nothing to do — on a chip they share with the H multi-exponentiation.
     const size_t lanes = gr.table ? std::min(total_buckets, n_entries_max) : total_buckets;
     bool plain = !d_gather;
-    for (unsigned i = 0; i < ns; ++i) plain = plain && sets[i].level_stride == 0 && sets[i].index_sub == 0;
+    for (unsigned i = 0; i < ns; ++i) plain = plain && sets[i].level_stride == 0 && sets[i].index_sub == 0 && !sets[i].remap;
     if (time_it) g_dominant_timer.begin(s);
     if (plain)
         hipLaunchKernelGGL((k_bucket_accum<F, true>), dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
@@ -1012,8 +1050,10 @@ static int window_table_build_t(WindowTable &t, const Affine<F> *d_bases, size_t
     if (!n) return ZKG_OK;
     Affine<F> *lv = t.buf.as<Affine<F>>();
     ZK_HIP(hipMemcpyAsync(lv, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, s));
-    for (int w = 1; w < t.W; ++w)
-        hipLaunchKernelGGL(k_table_level<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv + (size_t)(w - 1) * n, lv + (size_t)w * n, n, (uint32_t)c);
+    constexpr int K = sizeof(F) != sizeof(Fq) ? 2 : 4;                          // levels per launch (the K results stay in registers)
+    for (int w = 1; w < t.W; w += K)
+        hipLaunchKernelGGL((k_table_levels<F, K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv + (size_t)(w - 1) * n, lv + (size_t)w * n, n, (uint32_t)c,
+                           std::min(K, t.W - w));
     if (hipGetLastError() != hipSuccess) { set_error("window table launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
@@ -1021,11 +1061,23 @@ int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s) { return window_table_build_t<Fq2>(t, d_bases, n, c, s); }
 
 // ---- witness split: classification and the flat sum of the bases whose scalar is one ----------------------------------
-int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s) {
-    ZK_HIP(hipMemsetAsync(d_count, 0, 4, s));
-    if (n1) hipLaunchKernelGGL(k_classify, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, d_z, n1, d_tags, d_listed, d_count);
+int witness_classify(const Fr *d_z, size_t n1, uint8_t *d_tags, uint32_t *d_listed, uint32_t *d_count, hipStream_t s, const uint32_t *d_subset_pos) {
+    ZK_HIP(hipMemsetAsync(d_count, 0, 8, s));
+    if (n1) hipLaunchKernelGGL(k_classify, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, d_z, n1, d_tags, d_listed, d_count, d_subset_pos);
     return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
+template <class F> static int gather_points_t(const Affine<F> *d_src, const uint32_t *d_idx, size_t count, uint32_t index_sub, Affine<F> *d_out, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(k_gather_points<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, d_src, d_idx, count, index_sub, d_out);
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+int gather_points_g1(const G1Affine *d_src, const uint32_t *d_idx, size_t count, uint32_t index_sub, G1Affine *d_out, hipStream_t s) { return gather_points_t<Fq>(d_src, d_idx, count, index_sub, d_out, s); }
+int gather_points_g2(const G2Affine *d_src, const uint32_t *d_idx, size_t count, uint32_t index_sub, G2Affine *d_out, hipStream_t s) { return gather_points_t<Fq2>(d_src, d_idx, count, index_sub, d_out, s); }
+template <class F> static int scatter_points_t(const Affine<F> *d_src, const uint32_t *d_idx, size_t count, Affine<F> *d_out, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(k_scatter_points<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, d_src, d_idx, count, d_out);
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+int scatter_points_g1(const G1Affine *d_src, const uint32_t *d_idx, size_t count, G1Affine *d_out, hipStream_t s) { return scatter_points_t<Fq>(d_src, d_idx, count, d_out, s); }
+int scatter_points_g2(const G2Affine *d_src, const uint32_t *d_idx, size_t count, G2Affine *d_out, hipStream_t s) { return scatter_points_t<Fq2>(d_src, d_idx, count, d_out, s); }
 template <class F>
 static int ones_sum_launch_t(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *d_tags, size_t n1, hipStream_t s) {
     // lanes stride over the tags; per workgroup an 8-level LDS tree; one more workgroup per set sums the partials.  ~8 tagged elements per
@@ -1037,7 +1089,7 @@ static int ones_sum_launch_t(OnesSum &o, const MsmBases *sets, int nsets, const 
     if (!o.host) { if (!hip_ok(hipHostMalloc(&o.host, MSM_MAX_SETS * sizeof(G2), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return ZKG_ERROR; }
     XYZZ<F> *part = o.partials.as<XYZZ<F>>();
     ViewSet<F> views;
-    for (int i = 0; i < MSM_MAX_SETS; ++i) { const MsmBases &b = sets[i < nsets ? i : 0]; views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), 0, nullptr, b.index_sub, 1}; }
+    for (int i = 0; i < MSM_MAX_SETS; ++i) { const MsmBases &b = sets[i < nsets ? i : 0]; views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), 0, nullptr, b.index_sub, 1, nullptr}; }
     hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, views, d_tags, n1, part);
     hipLaunchKernelGGL(k_sum_partials<F>, dim3((unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, part, blocks);
     if (hipGetLastError() != hipSuccess) { set_error("ones-sum launch failed"); return ZKG_ERROR; }

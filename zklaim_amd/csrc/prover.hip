@@ -104,9 +104,19 @@ template <class F> struct CombTable {
 struct zkg_crs {
     uint32_t n = 0, l = 0, C = 0, log_m = 0; size_t m = 0;
     zk::DevCsr A, B, Cm;
-    // the five queries as per-window tables (level w = 2^(c w) P_i, level 0 = the query itself): windows share one bucket set, one
-    // reduction per multi-exponentiation and no doubling on the host (W x the key in HBM: 6 GB at 37 payloads, 2 % of the 288 GB)
-    zk::WindowTable A_query, B_g1, B_g2, H_query, L_query;
+    // Per-window tables (level w = 2^(c w) P_i, level 0 = the query itself): windows share one bucket set, one reduction per
+    // multi-exponentiation and no doubling on the host.  The H query gets one over all of its m - 1 points (its scalars are dense).
+    // The witness queries stay as uploaded (the flat sums over the ones read them) and get tables over a SUBSET of their elements only:
+    // the bucket method sees the non-bit variables of a witness, ~3 % of a credential's, and the same ones proof after proof.
+    zk::WindowTable H_query;
+    zk::DevBuf A_query, B_g1, B_g2, L_query;    // n + 1, n + 1, n + 1 (G2), n - l affine points
+    struct SubsetTables {
+        std::vector<uint8_t> member;            // host: is element i of z = [1 | w] covered
+        zk::DevBuf pos, idx;                    // device: position of every element in the subset (SUBSET_NONE = absent); the covered elements, ascending
+        size_t count = 0; uint32_t rebuilds = 0;
+        zk::WindowTable A, B1, B2, L;           // count points per level; the L table holds infinity for the constant and the public inputs
+    } sub;
+    int c_w = 0;                                // window bits of the witness tables
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
     CombTable<zk::Fq> alpha1_comb, beta1_comb, delta1_comb; CombTable<zk::Fq2> delta2_comb;
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
@@ -259,8 +269,10 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
     }
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, 4, s));
     // the multi_exp_with_mixed_addition split of z: tags, the indices of the non-bit elements, and their count (read by the host)
-    if (witness_classify(z, (size_t)crs->n + 1, S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), S.wcount.as<uint32_t>(), s)) return ZKG_ERROR;
-    ZK_HIP(hipMemcpyAsync(S.flag_host + 1, S.wcount.p, 4, hipMemcpyDeviceToHost, s));
+    // (and whether every one of them has its place in the witness tables: flag_host[2])
+    if (witness_classify(z, (size_t)crs->n + 1, S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), S.wcount.as<uint32_t>(), s,
+                         crs->sub.count ? crs->sub.pos.as<uint32_t>() : nullptr)) return ZKG_ERROR;
+    ZK_HIP(hipMemcpyAsync(S.flag_host + 1, S.wcount.p, 8, hipMemcpyDeviceToHost, s));
     if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident and split from here on
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
@@ -318,7 +330,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (S.ready) return ZKG_OK;
     const size_t n = crs->n, m = crs->m;
     bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * 32) == 0 &&
-              S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(4) == 0 &&
+              S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(8) == 0 &&
               hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
@@ -340,7 +352,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
         ok = ok && S.job_w1 && S.job_w2 && S.job_h &&
              hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
-            msm_job_set_window(S.job_w1, crs->A_query.c); msm_job_set_window(S.job_w2, crs->B_g2.c); msm_job_set_window(S.job_h, crs->H_query.c);
+            msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w); msm_job_set_window(S.job_h, crs->H_query.c);
         }
     }
     if (ok) {
@@ -371,7 +383,7 @@ using namespace zk;
 
 extern "C" {
 
-static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk) {
+static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = false, const std::function<bool()> &constraint_system_ready = nullptr) {
     if (!pk) { set_error("zkg_crs_upload: null pk"); return nullptr; }
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("zkg_crs_upload: no HIP device (call zkg_init)"); return nullptr; }
@@ -381,14 +393,17 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk) {
         ((size_t)cs.num_constraints + cs.num_inputs + 1) > shape.m || cs.num_inputs > cs.num_variables) {
         set_error("zkg_crs_upload: inconsistent sizes (domain must be 2^log_m or a step_radix2 size 2^(log_m-1) + 2^b)"); return nullptr;
     }
+    auto t_begin = std::chrono::steady_clock::now();
+    static const bool dbg_timing = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto lap = [&](const char *what) { if (dbg_timing) fprintf(stderr, "[zkg key upload] %-24s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     zkg_crs *crs = new zkg_crs();
     crs->n = cs.num_variables; crs->l = cs.num_inputs; crs->C = cs.num_constraints; crs->log_m = pk->log_m; crs->m = shape.m;
     const size_t n = crs->n, l = crs->l, m = crs->m;
-    bool ok = upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
-              upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
-    if (ok) {
-        // the queries become per-window tables (level 0 is the query as uploaded).  A, B_g1, B_g2 and L are indexed by the same witness and
-        // share one digit sort per proof, so they share one window size; H has its own.
+    bool ok = true;
+    {
+        // H becomes a per-window table (level 0 is the query as uploaded); A, B_g1, B_g2 and L go up as they are — their tables are built
+        // over the elements the first proofs list (subset_extend).  They are indexed by the same witness and share one digit sort per
+        // proof, so they share one window size; H has its own.
         static const char *cw = getenv("ZKG_TABLE_C_W"), *ch = getenv("ZKG_TABLE_C_H");                  // tuning aids
         // Witness queries: only the non-bit elements (~3 % of a credential's witness) reach the bucket method, so the window is sized for
         // ~0.03 n entries per window — a few per bucket: c = log2(n) - 5, at most 14 (measured flat between 10 and 14 at 8 and 37 payloads,
@@ -397,18 +412,28 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk) {
         // the fold and the reduction shrink with it.
         int lg_n = 0; while (((size_t)1 << (lg_n + 1)) <= n + 1) ++lg_n;
         const int c_w = cw ? atoi(cw) : std::min(14, std::max(8, lg_n - 5)), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
-        DevBuf stage;
-        auto table = [&](WindowTable &t, const uint64_t *src, size_t count, bool g2, int c) {
+        crs->c_w = c_w;
+        // a query: from the host (zkg_pk as the ABI hands it over) or already on the device (the blob path decompresses there)
+        auto query = [&](DevBuf &q, const uint64_t *src, size_t count, bool g2) {
             const size_t bytes = count * (g2 ? 128 : 64);
-            if (upload(stage, src, bytes)) return false;
-            int rc = g2 ? window_table_build_g2(t, stage.as<G2Affine>(), count, c, nullptr) : window_table_build_g1(t, stage.as<G1Affine>(), count, c, nullptr);
-            return rc == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);              // `stage` is reused by the next query
+            if (q.reserve(bytes + 16)) return false;
+            return !bytes || hip_ok(hipMemcpy(q.p, src, bytes, queries_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "query upload", __FILE__, __LINE__);
         };
         ok = c_w >= 2 && c_w <= 16 && c_h >= 2 && c_h <= 16 &&
-             table(crs->A_query, pk->A_query, n + 1, false, c_w) && table(crs->B_g1, pk->B_g1, n + 1, false, c_w) && table(crs->B_g2, pk->B_g2, n + 1, true, c_w) &&
-             table(crs->L_query, pk->L_query, n - l, false, c_w) && table(crs->H_query, pk->H_query, m - 1, false, c_h);
-        stage.release();
+             query(crs->A_query, pk->A_query, n + 1, false) && query(crs->B_g1, pk->B_g1, n + 1, false) && query(crs->B_g2, pk->B_g2, n + 1, true) &&
+             query(crs->L_query, pk->L_query, n - l, false);
+        if (ok) {
+            DevBuf stage; const G1Affine *h_dev = (const G1Affine *)pk->H_query;
+            if (!queries_on_device) { ok = upload(stage, pk->H_query, (m - 1) * 64) == 0; h_dev = stage.as<G1Affine>(); }
+            ok = ok && window_table_build_g1(crs->H_query, h_dev, m - 1, c_h, nullptr) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+            stage.release();
+        }
     }
+    lap("queries up, H table built");
+    // the constraint system last: the blob path parses it on another thread while the GPU decompresses the points and builds the table
+    if (ok && constraint_system_ready && !constraint_system_ready()) ok = false;
+    ok = ok && upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
+         upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
     if (ok) {                                                                // rows left to the wavefront-per-row kernel
         std::vector<uint32_t> lr;
         const uint32_t *rps[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr};
@@ -432,7 +457,9 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk) {
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
         ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0;
     }
+    lap("comb tables + domain");
     ok = ok && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) && slot_create(crs, crs->slot[0]) == ZKG_OK;
+    lap("prover slot created");
     if (!ok) { zkg_crs_free(crs); return nullptr; }
     return crs;
 }
@@ -448,7 +475,8 @@ void zkg_crs_free(zkg_crs *crs) {
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
                       &crs->coset_over_m, &crs->long_rows})
         b->release();
-    for (WindowTable *t : {&crs->A_query, &crs->B_g1, &crs->B_g2, &crs->H_query, &crs->L_query}) t->release();
+    for (WindowTable *t : {&crs->H_query, &crs->sub.A, &crs->sub.B1, &crs->sub.B2, &crs->sub.L}) t->release();
+    for (DevBuf *b : {&crs->A_query, &crs->B_g1, &crs->B_g2, &crs->L_query, &crs->sub.pos, &crs->sub.idx}) b->release();
     for (ProverSlot &S : crs->slot) slot_destroy(S);
     delete crs;
 }
@@ -481,7 +509,42 @@ static const int g_witness_start = [] { const char *e = getenv("ZKG_WITNESS_STAR
 static void lap(const ProverSlot &S, const char *what) {
     if (g_dbg_timing) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
 }
-static MsmBases table_set(const WindowTable &t, uint32_t index_sub) { MsmBases b; b.p = t.buf.p; b.g2 = t.g2; b.level_stride = t.n; b.index_sub = index_sub; return b; }
+static MsmBases table_set(const WindowTable &t, bool g2, uint32_t index_sub, const uint32_t *remap = nullptr) {       // (a table not built yet is empty, not G1)
+    MsmBases b; b.p = t.buf.p; b.g2 = g2; b.level_stride = t.n; b.index_sub = index_sub; b.remap = remap; return b;
+}
+static MsmBases query_set(const DevBuf &q, bool g2, uint32_t index_sub) { MsmBases b; b.p = q.p; b.g2 = g2; b.index_sub = index_sub; return b; }
+
+// The witness tables grow to cover `listed` more elements (the first proof on a key; later only when a witness has a non-bit value where
+// every earlier one had a bit).  Host: membership -> ascending element list and positions; device: level 0 gathered from the queries, then
+// the levels.  Runs on the helper thread with the ones-sum stream, which has nothing of this proof queued yet.
+static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
+    zkg_crs::SubsetTables &T = crs->sub;
+    const size_t n1 = (size_t)crs->n + 1; hipStream_t s = S.stream_o;
+    std::vector<uint32_t> li(listed);
+    ZK_HIP(hipMemcpyAsync(li.data(), S.wlisted.p, listed * 4, hipMemcpyDeviceToHost, s));
+    ZK_HIP(hipStreamSynchronize(s));
+    if (T.member.empty()) T.member.assign(n1, 0);
+    for (uint32_t i : li) { if (i >= n1) { set_error("prover: witness split out of range"); return ZKG_ERROR; } T.member[i] = 1; }
+    std::vector<uint32_t> pos(n1, SUBSET_NONE), idx;
+    idx.reserve(listed + T.count);
+    for (size_t i = 0; i < n1; ++i) if (T.member[i]) { pos[i] = (uint32_t)idx.size(); idx.push_back((uint32_t)i); }
+    const size_t count = idx.size();
+    if (T.pos.reserve(n1 * 4) || T.idx.reserve(count * 4 + 16)) return ZKG_ERROR;
+    ZK_HIP(hipMemcpyAsync(T.pos.p, pos.data(), n1 * 4, hipMemcpyHostToDevice, s));
+    ZK_HIP(hipMemcpyAsync(T.idx.p, idx.data(), count * 4, hipMemcpyHostToDevice, s));
+    DevBuf stage;
+    if (stage.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
+    const uint32_t *d_idx = T.idx.as<uint32_t>();
+    int rc = gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.A, stage.as<G1Affine>(), count, crs->c_w, s) ||
+             gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.B1, stage.as<G1Affine>(), count, crs->c_w, s) ||
+             gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), stage.as<G1Affine>(), s) || window_table_build_g1(T.L, stage.as<G1Affine>(), count, crs->c_w, s) ||
+             gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage.as<G2Affine>(), s) || window_table_build_g2(T.B2, stage.as<G2Affine>(), count, crs->c_w, s);
+    const bool synced = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);       // pos / idx (host vectors) and `stage` go out of scope
+    stage.release();
+    if (rc || !synced) { T.count = 0; return ZKG_ERROR; }
+    T.count = count; ++T.rebuilds;
+    return ZKG_OK;
+}
 // event slots: 0 witness resident + split done, 1 mat-vec done, 2 H coefficients done, 3 satisfiability flag landed,
 //              4-5 G1 witness job, 6-7 G2 witness job, 8-9 H job
 static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness, const uint64_t r_[4], const uint64_t s_[4], bool check) {
@@ -499,13 +562,18 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         const size_t listed = S.flag_host[1];
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
         const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
-        const MsmBases g1[3] = {table_set(crs->A_query, 0), table_set(crs->B_g1, 0), table_set(crs->L_query, (uint32_t)(l + 1))}, b2 = table_set(crs->B_g2, 0);
+        if (listed && (S.flag_host[2] || !crs->sub.count) && subset_extend(crs, S, listed)) return ZKG_ERROR;
+        const uint32_t *pos = crs->sub.pos.as<uint32_t>();
+        // bucket method: the subset tables, addressed through the element positions; flat sums over the ones: the queries as uploaded
+        const MsmBases g1[3] = {table_set(crs->sub.A, false, 0, pos), table_set(crs->sub.B1, false, 0, pos), table_set(crs->sub.L, false, 0, pos)}, b2 = table_set(crs->sub.B2, true, 0, pos);
+        const MsmBases o1[3] = {query_set(crs->A_query, false, 0), query_set(crs->B_g1, false, 0), query_set(crs->L_query, false, (uint32_t)(l + 1))},
+                       o2 = query_set(crs->B_g2, true, 0);
         // ZKG_WITNESS_START (tuning aid): which event the witness streams wait for — 0 the split (default), 1 the mat-vec, 2 the transforms
         hipEvent_t go = S.ev[g_witness_start];
         {
             hipStream_t js = msm_job_stream(S.job_w2);                         // G2 first: the longest chains
             ZK_HIP(hipStreamWaitEvent(S.stream_o, go, 0));
-            if (ones_sum_launch(S.ones_g2, &b2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            if (ones_sum_launch(S.ones_g2, &o2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
             (void)hipEventRecord(S.ev[10], S.stream_o);                        // the G2 sum has landed (the G1 sums follow on the same stream)
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[6], js);
@@ -515,7 +583,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         }
         {
             hipStream_t js = msm_job_stream(S.job_w1);
-            if (ones_sum_launch(S.ones_g1, g1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            if (ones_sum_launch(S.ones_g1, o1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[4], js);
             if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
@@ -532,7 +600,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     if (rc == ZKG_OK) {
         hipStream_t js = msm_job_stream(S.job_h);                              // == S.stream
         (void)hipEventRecord(S.ev[8], js);
-        const MsmBases h = table_set(crs->H_query, 0);
+        const MsmBases h = table_set(crs->H_query, false, 0);
         rc = msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true);
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
@@ -649,3 +717,8 @@ int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
 }
 
 }  // extern "C"
+
+// the blob path (codec.hip): queries already on the device, constraint system possibly still being parsed
+zkg_crs *crs_upload_device_queries(const zkg_pk *pk, const std::function<bool()> &constraint_system_ready) {
+    return zkg_crs_upload_impl(pk, true, constraint_system_ready);
+}
