@@ -131,6 +131,37 @@ struct Builder {
         for (auto &c : cons) push_row(m, which == 0 ? c.a : which == 1 ? c.b : c.c, scratch);
     }
     void export_csr(Csr &A, Csr &B, Csr &C) const { export_matrix(0, A); export_matrix(1, B); export_matrix(2, C); }
+    // The same three matrices, rows cut into `chunks` ranges per matrix: run(tasks, f) executes f(0..tasks-1) (a thread pool's parallel-for).
+    // A range is exported into a matrix of its own and the pieces are then joined — rows are independent, the result is export_matrix's.
+    template <class Run> void export_csr_chunked(Csr *out[3], int chunks, Run run) const {
+        const size_t rows = cons.size();
+        if (chunks < 1) chunks = 1;
+        std::vector<Csr> piece((size_t)3 * chunks);
+        run(3 * chunks, [&](int task) {
+            const int which = task / chunks, ch = task % chunks;
+            const size_t lo = rows * (size_t)ch / chunks, hi = rows * (size_t)(ch + 1) / chunks;
+            Csr &m = piece[task];
+            m.rowptr.assign(1, 0); m.rowptr.reserve(hi - lo + 1);
+            size_t terms = 0;
+            for (size_t r = lo; r < hi; ++r) terms += (which == 0 ? cons[r].a : which == 1 ? cons[r].b : cons[r].c).len;
+            m.col.reserve(terms); m.val.reserve(4 * terms);
+            std::vector<std::pair<Var, Fr>> scratch;
+            for (size_t r = lo; r < hi; ++r) push_row(m, which == 0 ? cons[r].a : which == 1 ? cons[r].b : cons[r].c, scratch);
+        });
+        run(3, [&](int which) {
+            Csr &m = *out[which];
+            size_t terms = 0;
+            for (int ch = 0; ch < chunks; ++ch) terms += piece[(size_t)which * chunks + ch].col.size();
+            m.rowptr.assign(1, 0); m.rowptr.reserve(rows + 1); m.col.clear(); m.col.reserve(terms); m.val.clear(); m.val.reserve(4 * terms);
+            for (int ch = 0; ch < chunks; ++ch) {
+                const Csr &pc = piece[(size_t)which * chunks + ch];
+                const uint32_t base = (uint32_t)m.col.size();
+                for (size_t r = 1; r < pc.rowptr.size(); ++r) m.rowptr.push_back(base + pc.rowptr[r]);
+                m.col.insert(m.col.end(), pc.col.begin(), pc.col.end());
+                m.val.insert(m.val.end(), pc.val.begin(), pc.val.end());
+            }
+        });
+    }
 };
 
 }}  // namespace zk::circuit

@@ -532,17 +532,22 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     if (T.pos.reserve(n1 * 4) || T.idx.reserve(count * 4 + 16)) return ZKG_ERROR;
     ZK_HIP(hipMemcpyAsync(T.pos.p, pos.data(), n1 * 4, hipMemcpyHostToDevice, s));
     ZK_HIP(hipMemcpyAsync(T.idx.p, idx.data(), count * 4, hipMemcpyHostToDevice, s));
-    DevBuf stage;
-    if (stage.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
+    // the G2 table on the B_g2 job's stream (idle as well), beside the three G1 tables: a few thousand points per launch are latency chains
+    DevBuf stage, stage2;
+    if (stage.reserve(count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
     const uint32_t *d_idx = T.idx.as<uint32_t>();
-    int rc = gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.A, stage.as<G1Affine>(), count, crs->c_w, s) ||
+    hipStream_t s2 = msm_job_stream(S.job_w2);
+    bool ok = hip_ok(hipEventRecord(S.ev[11], s), "event", __FILE__, __LINE__) && hip_ok(hipStreamWaitEvent(s2, S.ev[11], 0), "wait", __FILE__, __LINE__);   // idx is up
+    int rc = !ok || gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage2.as<G2Affine>(), s2) || window_table_build_g2(T.B2, stage2.as<G2Affine>(), count, crs->c_w, s2) ||
+             gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.A, stage.as<G1Affine>(), count, crs->c_w, s) ||
              gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.B1, stage.as<G1Affine>(), count, crs->c_w, s) ||
-             gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), stage.as<G1Affine>(), s) || window_table_build_g1(T.L, stage.as<G1Affine>(), count, crs->c_w, s) ||
-             gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage.as<G2Affine>(), s) || window_table_build_g2(T.B2, stage.as<G2Affine>(), count, crs->c_w, s);
-    const bool synced = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);       // pos / idx (host vectors) and `stage` go out of scope
-    stage.release();
+             gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), stage.as<G1Affine>(), s) || window_table_build_g1(T.L, stage.as<G1Affine>(), count, crs->c_w, s);
+    const bool synced1 = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__), synced2 = hip_ok(hipStreamSynchronize(s2), "sync", __FILE__, __LINE__);
+    const bool synced = synced1 && synced2;                                     // (both streams waited for: host vectors and staging go out of scope)
+    stage.release(); stage2.release();
     if (rc || !synced) { T.count = 0; return ZKG_ERROR; }
     T.count = count; ++T.rebuilds;
+    if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u)\n", count, n1, T.rebuilds);
     return ZKG_OK;
 }
 // event slots: 0 witness resident + split done, 1 mat-vec done, 2 H coefficients done, 3 satisfiability flag landed,

@@ -223,7 +223,11 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         for (size_t i = 0; i < k; ++i) payload_gadgets(pb, i);
     }
     lap("payload sub-circuits");
-    if (pb.recording) { Builder::Csr *ms[3] = {&ck->A, &ck->B, &ck->C}; host_parallel_for(3, [&](int m) { pb.export_matrix(m, *ms[m]); }); }
+    if (pb.recording) {
+        Builder::Csr *ms[3] = {&ck->A, &ck->B, &ck->C};
+        const int chunks = getenv("ZKG_SERIAL_CIRCUIT") ? 1 : (int)std::min<size_t>(16, pb.cons.size() / 8192 + 1);
+        pb.export_csr_chunked(ms, chunks, [](int tasks, const std::function<void(int)> &f) { host_parallel_for(tasks, f); });
+    }
     lap("CSR exported");
     ck->has_witness = with_witness;             // the witness is pb.val[1..] itself: Fr is the ABI's 4 x u64 Montgomery element
     return ck;
