@@ -116,7 +116,7 @@ struct zkg_crs {
         size_t count = 0; uint32_t rebuilds = 0;
         zk::WindowTable A, B1, B2, L;           // count points per level; the L table holds infinity for the constant and the public inputs
     } sub;
-    int c_w = 0;                                // window bits of the witness tables
+    int c_w = 8, c_w_forced = 0;                // window bits of the witness tables (set when they are built), ZKG_TABLE_C_W override
     zk::G1Affine alpha_g1, beta_g1, delta_g1; zk::G2Affine beta_g2, delta_g2;
     CombTable<zk::Fq> alpha1_comb, beta1_comb, delta1_comb; CombTable<zk::Fq2> delta2_comb;
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
@@ -405,21 +405,16 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = f
         // over the elements the first proofs list (subset_extend).  They are indexed by the same witness and share one digit sort per
         // proof, so they share one window size; H has its own.
         static const char *cw = getenv("ZKG_TABLE_C_W"), *ch = getenv("ZKG_TABLE_C_H");                  // tuning aids
-        // Witness queries: only the non-bit elements (~3 % of a credential's witness) reach the bucket method, so the window is sized for
-        // ~0.03 n entries per window — a few per bucket: c = log2(n) - 5, at most 14 (measured flat between 10 and 14 at 8 and 37 payloads,
-        // 5 % slower at 16).  Small bucket sets keep this latency-bound work light: the digit sort's LDS histogram is 2^(c-1) counters
-        // (8 KB at 8 payloads instead of the 128 KB of c = 16, which made its workgroups wait for an empty CU while the transforms ran),
-        // the fold and the reduction shrink with it.
-        int lg_n = 0; while (((size_t)1 << (lg_n + 1)) <= n + 1) ++lg_n;
-        const int c_w = cw ? atoi(cw) : std::min(14, std::max(8, lg_n - 5)), c_h = ch ? atoi(ch) : table_window_bits(m - 1);
-        crs->c_w = c_w;
+        // The witness tables' window is chosen when they are built, from the number of elements they cover (subset_extend); 0 = that rule.
+        const int c_w = cw ? atoi(cw) : 0, c_h = ch ? atoi(ch) : table_window_bits(m - 1);
+        crs->c_w_forced = c_w;
         // a query: from the host (zkg_pk as the ABI hands it over) or already on the device (the blob path decompresses there)
         auto query = [&](DevBuf &q, const uint64_t *src, size_t count, bool g2) {
             const size_t bytes = count * (g2 ? 128 : 64);
             if (q.reserve(bytes + 16)) return false;
             return !bytes || hip_ok(hipMemcpy(q.p, src, bytes, queries_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "query upload", __FILE__, __LINE__);
         };
-        ok = c_w >= 2 && c_w <= 16 && c_h >= 2 && c_h <= 16 &&
+        ok = (c_w == 0 || (c_w >= 2 && c_w <= 16)) && c_h >= 2 && c_h <= 16 &&
              query(crs->A_query, pk->A_query, n + 1, false) && query(crs->B_g1, pk->B_g1, n + 1, false) && query(crs->B_g2, pk->B_g2, n + 1, true) &&
              query(crs->L_query, pk->L_query, n - l, false);
         if (ok) {
@@ -532,6 +527,14 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     if (T.pos.reserve(n1 * 4) || T.idx.reserve(count * 4 + 16)) return ZKG_ERROR;
     ZK_HIP(hipMemcpyAsync(T.pos.p, pos.data(), n1 * 4, hipMemcpyHostToDevice, s));
     ZK_HIP(hipMemcpyAsync(T.idx.p, idx.data(), count * 4, hipMemcpyHostToDevice, s));
+    // Window size: only the non-bit elements of a witness reach the bucket method — a credential's values, packings and public inputs,
+    // ~30 per payload, a thousand of a million variables at 37 payloads — so the window is sized for `count` entries per window, about one
+    // per bucket: c = log2(count) + 2 within [10, 14] (measured flat between 10 and 14 at 8 and 37 payloads, 3 - 5 % slower at 16).  Small
+    // bucket sets keep this latency-bound work light: the digit sort's LDS histogram is 2^(c-1) counters, the fold and the reduction
+    // shrink with it.
+    int lg_count = 0; while (((size_t)1 << (lg_count + 1)) <= count) ++lg_count;
+    crs->c_w = crs->c_w_forced ? crs->c_w_forced : std::min(14, std::max(10, lg_count + 2));
+    msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w);
     // the G2 table on the B_g2 job's stream (idle as well), beside the three G1 tables: a few thousand points per launch are latency chains
     DevBuf stage, stage2;
     if (stage.reserve(count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
