@@ -100,6 +100,8 @@ static constexpr int MSM_MAX_SETS = 4;                      // base sets sharing
 // remap (optional, device): element i of the scalars stands for entry remap[i] of the set — a table that holds only a subset of the key's
 // elements (the prover's witness tables cover the non-bit variables only).
 struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; const uint32_t *remap = nullptr; };
+// CSR matrices A, B, C handed from a circuit to the key generator without a copy
+struct OwnedCsr { std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3]; };
 struct WindowTable { DevBuf buf; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); n = 0; } };
 int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s);
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s);

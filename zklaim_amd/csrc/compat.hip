@@ -32,6 +32,9 @@ size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
 int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len);
 }
 
+zkg_keypair *groth16_setup_owned(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu);    // setup_verify.hip
+void circuit_release_csr(zkg_circuit *c, zk::OwnedCsr &out);                                                            // zklaim_circuit.hip
+
 namespace {
 
 std::mutex g_mu;
@@ -110,8 +113,17 @@ static int libsnark_trusted_setup_impl(zklaim_ctx *ctx) {
     if (!ck) return ZKLAIM_ERROR;
     lap("circuit built");
     zkg_r1cs cs;
-    zkg_keypair *kp = zkg_circuit_r1cs(ck, &cs) == 0 ? zkg_groth16_setup(&cs, nullptr) : nullptr;
-    zkg_circuit_free(ck);
+    zkg_keypair *kp = nullptr;
+    if (zkg_circuit_r1cs(ck, &cs) == 0) {
+        // the keypair takes the circuit's CSR matrices over (no copy), and what is left of the circuit — the constraint arena and the
+        // variable store — is destroyed on a side thread while the GPU turns the generator's scalars into points
+        zk::OwnedCsr csr;
+        circuit_release_csr(ck, csr);
+        cs.a_rowptr = cs.b_rowptr = cs.c_rowptr = nullptr; cs.a_col = cs.b_col = cs.c_col = nullptr; cs.a_val = cs.b_val = cs.c_val = nullptr;
+        bool freed = false;
+        kp = groth16_setup_owned(&cs, &csr, [&] { zkg_circuit_free(ck); freed = true; });
+        if (!freed) zkg_circuit_free(ck);                        // the generator failed before its GPU phase
+    } else zkg_circuit_free(ck);
     if (!kp) return ZKLAIM_ERROR;
     lap("keypair generated");
     size_t vk_len = zkg_keypair_vk_blob(kp, nullptr, 0), pk_len = zkg_keypair_pk_blob(kp, nullptr, 0);
@@ -138,20 +150,28 @@ static int libsnark_prove_impl(zklaim_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return ZKLAIM_ERROR;
     const uint64_t key = sampled_digest(ctx->pk, ctx->pk_size);
-    auto upload = [&](const Digest128 &full) -> zkg_crs * {
-        zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
-        if (!c) return nullptr;
+    auto adopt = [&](zkg_crs *c, const Digest128 &full) -> zkg_crs * {          // a freshly loaded key into the cache (at most four resident)
         auto old = g_crs_cache.find(key);
         if (old != g_crs_cache.end()) { zkg_crs_free(old->second.crs); g_crs_cache.erase(old); }
         if (g_crs_cache.size() >= 4) { for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs); g_crs_cache.clear(); }
         g_crs_cache[key] = {ctx->pk_size, full, c};
         return c;
     };
+    auto upload = [&](const Digest128 &full) -> zkg_crs * {
+        zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
+        return c ? adopt(c, full) : nullptr;
+    };
     zkg_crs *crs = nullptr;
     bool speculative = false;                                    // a cache hit by the sampled digest: confirmed by the full one below
     auto it = g_crs_cache.find(key);
     if (it != g_crs_cache.end() && it->second.size == ctx->pk_size) { crs = it->second.crs; speculative = true; }
-    else if (!(crs = upload(full_digest(ctx->pk, ctx->pk_size)))) return ZKLAIM_ERROR;
+    else {                                                       // a new key: its full digest (every byte) is computed while the key loads
+        std::future<Digest128> digest = std::async(std::launch::async, [&] { return full_digest(ctx->pk, ctx->pk_size); });
+        zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
+        const Digest128 full = digest.get();
+        if (!c) return ZKLAIM_ERROR;
+        crs = adopt(c, full);
+    }
     // the witness only: the constraint system already sits on the GPU inside the resident key, and pb.is_satisfied()
     // (snark.cpp:121-124) is evaluated there, fused with the R1CS mat-vec of the prover (check_satisfied = 1)
     zkg_circuit *ck = zkg_zklaim_witness_new(ctx);

@@ -85,13 +85,26 @@ struct ProverSlot {
 template <class F> struct CombTable {
     std::vector<zk::Affine<F>> t;               // 64 x 15
     void build(const zk::Affine<F> &base) {
-        t.assign(64 * 15, zk::Affine<F>::inf());
+        // all 960 multiples in XYZZ first, then ONE inversion for the lot (Montgomery's trick over their ZZZ): a to_affine per entry was
+        // 960 Fermat inversions, 10 - 25 ms of every key load
+        std::vector<zk::XYZZ<F>> p(64 * 15);
         zk::XYZZ<F> row = zk::XYZZ<F>::from_affine(base);                        // 16^j * P
         for (int j = 0; j < 64; ++j) {
             zk::XYZZ<F> cur = row;
-            zk::Affine<F> row_aff = row.to_affine();
-            for (int d = 1; d <= 15; ++d) { t[j * 15 + d - 1] = cur.to_affine(); cur.madd(row_aff); }
+            for (int d = 1; d <= 15; ++d) { p[j * 15 + d - 1] = cur; cur.add(row); }
             for (int k = 0; k < 4; ++k) row = row.dbl();
+        }
+        t.assign(64 * 15, zk::Affine<F>::inf());
+        std::vector<F> pre(p.size());
+        F run = F::one();
+        for (size_t i = 0; i < p.size(); ++i) { pre[i] = run; if (!p[i].is_inf()) run = run * p[i].zzz; }
+        F inv = run.inverse();
+        for (size_t i = p.size(); i-- > 0;) {
+            if (p[i].is_inf()) continue;
+            F zi = inv * pre[i];                                                 // 1 / ZZZ_i
+            inv = inv * p[i].zzz;
+            F z1 = zi * p[i].zz, zi2 = z1.sqr();                                 // ZZ / ZZZ = 1 / Z;  1 / ZZ
+            t[i] = zk::Affine<F>{p[i].x * zi2, p[i].y * zi};
         }
     }
     zk::XYZZ<F> mul(const uint32_t k[8]) const {                                  // canonical little-endian scalar

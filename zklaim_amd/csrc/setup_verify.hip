@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <functional>
 #include <mutex>
+#include <thread>
 #include <chrono>
 #include "../../include/zkg.h"
 #include "host/serialize.hpp"
@@ -89,17 +90,26 @@ void fr_limbs(const Fr &x, uint32_t out[8]) { Fr c = x.from_mont(); memcpy(out, 
 
 extern "C" {
 
-zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5 x 4 canonical limbs: t, alpha, beta, gamma, delta; NULL = random */) {
-    if (!cs || !cs->a_rowptr || !cs->b_rowptr || !cs->c_rowptr) { set_error("zkg_groth16_setup: null constraint system"); return nullptr; }
+// The generator proper.  The constraint system comes either as the ABI's view (copied) or — `owned` — as CSR vectors the caller gives up
+// (the seam's circuit: 100 MB at 20 payloads that would otherwise be copied and then freed twice); `under_gpu` runs on a thread of its own
+// while the GPU turns the scalars into points (the seam destroys its circuit there).
+static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapdoor, OwnedCsr *owned, const std::function<void()> &under_gpu) {
+    if (!cs || (!owned && (!cs->a_rowptr || !cs->b_rowptr || !cs->c_rowptr))) { set_error("zkg_groth16_setup: null constraint system"); return nullptr; }
     zkg_keypair *kp = new zkg_keypair();
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
     auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg setup] %-28s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     kp->n = cs->num_variables; kp->l = cs->num_inputs; kp->C = cs->num_constraints;
     const size_t n = kp->n, l = kp->l, C = kp->C;
-    copy_csr(kp->rp[0], kp->col[0], kp->val[0], cs->a_rowptr, cs->a_col, cs->a_val, kp->C);
-    copy_csr(kp->rp[1], kp->col[1], kp->val[1], cs->b_rowptr, cs->b_col, cs->b_val, kp->C);
-    copy_csr(kp->rp[2], kp->col[2], kp->val[2], cs->c_rowptr, cs->c_col, cs->c_val, kp->C);
+    if (owned) {
+        for (int k = 0; k < 3; ++k) { kp->rp[k].swap(owned->rp[k]); kp->col[k].swap(owned->col[k]); kp->val[k].swap(owned->val[k]); }
+        for (int k = 0; k < 3; ++k)
+            if (kp->rp[k].size() != C + 1 || kp->col[k].size() != kp->rp[k][C] || kp->val[k].size() != 4 * kp->col[k].size()) { set_error("zkg_groth16_setup: inconsistent CSR"); delete kp; return nullptr; }
+    } else {
+        copy_csr(kp->rp[0], kp->col[0], kp->val[0], cs->a_rowptr, cs->a_col, cs->a_val, kp->C);
+        copy_csr(kp->rp[1], kp->col[1], kp->val[1], cs->b_rowptr, cs->b_col, cs->b_val, kp->C);
+        copy_csr(kp->rp[2], kp->col[2], kp->val[2], cs->c_rowptr, cs->c_col, cs->c_val, kp->C);
+    }
     {   // swap_AB_if_beneficial: count the variables each of A and B touches
         std::vector<char> ta(n + 1, 0), tb(n + 1, 0);
         for (uint32_t c : kp->col[0]) ta[c] = 1;
@@ -153,6 +163,9 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     });
     lap("qap evaluation + scalars");
     // ---- scalars -> points (GPU fixed-base batches)
+    std::thread side;
+    if (under_gpu) side = std::thread([&] { try { under_gpu(); } catch (...) {} });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_side{side};
     G1Affine g1 = g1_generator(); G2Affine g2 = g2_generator();
     std::vector<G1Affine> small1; std::vector<G2Affine> small2;
     bool ok = batch_points<G1Affine>(fixed_base_g1, g1, {alpha, beta, delta}, small1) == 0 && batch_points<G2Affine>(fixed_base_g2, g2, {beta, delta, gamma}, small2) == 0 &&
@@ -176,6 +189,9 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
     v.A_query = (const uint64_t *)kp->A_query.data(); v.B_g1 = (const uint64_t *)kp->B_g1.data(); v.B_g2 = (const uint64_t *)kp->B_g2.data();
     v.H_query = (const uint64_t *)kp->H_query.data(); v.L_query = (const uint64_t *)kp->L_query.data();
     return kp;
+}
+zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5 x 4 canonical limbs: t, alpha, beta, gamma, delta; NULL = random */) {
+    return groth16_setup_impl(cs, trapdoor, nullptr, nullptr);
 }
 
 void zkg_keypair_free(zkg_keypair *kp) { delete kp; }
@@ -343,3 +359,8 @@ int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
 }
 
 }  // extern "C"
+
+// the seam's entry (compat.hip): sizes in `cs`, the CSR arrays given up in `owned`
+zkg_keypair *groth16_setup_owned(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu) {
+    return groth16_setup_impl(cs, nullptr, owned, under_gpu);
+}

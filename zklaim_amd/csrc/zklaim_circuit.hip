@@ -309,3 +309,9 @@ size_t zkg_zklaim_input_map(const zklaim_ctx *ctx, uint64_t *out, size_t cap_ele
 }
 
 }  // extern "C"
+
+// the circuit gives up its CSR matrices (the seam's key generation: no copy of 100 MB); zkg_circuit_r1cs is empty afterwards
+void circuit_release_csr(zkg_circuit *c, zk::OwnedCsr &out) {
+    Builder::Csr *ms[3] = {&c->A, &c->B, &c->C};
+    for (int k = 0; k < 3; ++k) { out.rp[k].swap(ms[k]->rowptr); out.col[k].swap(ms[k]->col); out.val[k].swap(ms[k]->val); }
+}
