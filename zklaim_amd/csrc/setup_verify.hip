@@ -168,6 +168,12 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_side{side};
     G1Affine g1 = g1_generator(); G2Affine g2 = g2_generator();
     std::vector<G1Affine> small1; std::vector<G2Affine> small2;
+    // the result vectors (250 MB at 20 payloads) get their pages on the pool, side by side, instead of one after the other inside the batches
+    static const bool no_prefault = getenv("ZKG_NO_PREFAULT") != nullptr;
+    if (!no_prefault) host_parallel_for(5, [&](int i) {
+        if (i == 0) kp->B_g2.resize(Bt.size()); else if (i == 1) kp->A_query.resize(At.size()); else if (i == 2) kp->B_g1.resize(Bt.size());
+        else if (i == 3) kp->H_query.resize(Hs.size()); else kp->L_query.resize(Ls.size());
+    });
     bool ok = batch_points<G1Affine>(fixed_base_g1, g1, {alpha, beta, delta}, small1) == 0 && batch_points<G2Affine>(fixed_base_g2, g2, {beta, delta, gamma}, small2) == 0 &&
               batch_points<G1Affine>(fixed_base_g1, g1, At, kp->A_query) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Bt, kp->B_g1) == 0 &&
               batch_points<G2Affine>(fixed_base_g2, g2, Bt, kp->B_g2) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Hs, kp->H_query) == 0 &&
