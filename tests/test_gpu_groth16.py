@@ -86,6 +86,37 @@ def test_prove_from_pk_blob(zkg, oracle, case):
             zkg.Crs(blob=blob[:head] + bogus + blob[nl:], m=case["m"])
 
 
+def test_truncated_and_damaged_pk_blobs_are_refused(zkg, oracle):
+    """The blob loader walks the point sections on the calling thread and the constraint-system text on a thread of its own while
+    the GPU decompresses: a blob cut at any place — inside the head, a query, the sparse B index list, a term count, a coefficient —
+    or with a damaged constraint system must come back as an error (never a crash, a hang or a key), and the loader must still work
+    afterwards."""
+    case = CASES[1]
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    ocs = oracle.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep)
+    blob = oracle.pk_write_blob(oracle.make_pk(ocs, pts))
+    n = len(blob)
+    cuts = sorted(set([1, 33, 100, 269, 270, n - 1, n - 2, n - 33, n - 40] + [int(n * f / 37) for f in range(1, 37)]))
+    for cut in cuts:
+        with pytest.raises(zkg.ZkgError):
+            zkg.Crs(blob=blob[:cut], m=case["m"])
+    # the constraint-system section: a term index beyond the variable count, a term count that overruns the blob, a non-digit
+    tail = blob.rindex(b"\n", 0, n - 40)                     # a newline inside the last constraints
+    for bad in (blob[:tail - 1] + b"9" * 9 + blob[tail:], blob[:tail - 1] + b"x" + blob[tail:]):
+        try:
+            crs = zkg.Crs(blob=bad, m=case["m"])
+            rc, proof = crs.prove(w, r, s)                     # (an edit that happens to stay well-formed gives another system: no golden proof)
+            assert rc != 0 or proof.hex() != case["proof_hex"]
+            crs.free()
+        except zkg.ZkgError:
+            pass
+    crs = zkg.Crs(blob=blob, m=case["m"])
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    crs.free()
+
+
 def test_pk_blob_zklaim_shaped(zkg, oracle):
     from zklaim_amd import synth
     log_m = 12
