@@ -174,6 +174,11 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk);
  * on the GPU.  The domain is recovered from |H_query| + 1 (2^k, or a step_radix2 size 2^a + 2^b).  Counts inside the blob are
  * bounded by the bytes that follow them before anything is sized by them: a malformed blob is an error return, never a fault. */
 zkg_crs *zkg_crs_upload_blob(const void *pk_blob, size_t len);
+/* The host half of that loader alone (no GPU, no zkg_init): walks the sections, the sparse B index list and every constraint's terms of
+ * a pk blob and reports its sizes — out[8] (optional): A_query entries, B_query values, H_query entries, L_query entries, public inputs,
+ * constraints, terms in A + B + C, evaluation domain size.  ZKG_OK / ZKG_ERROR; what the reference's libsnark_import_pk would have
+ * thrown on (libsnark_wrapper.cpp:160-168) is an error return here. */
+int zkg_pk_blob_inspect(const void *pk_blob, size_t len, uint64_t out[8]);
 void     zkg_crs_free(zkg_crs *crs);
 uint32_t zkg_crs_num_variables(const zkg_crs *crs);   /* n of the resident key (the witness length zkg_groth16_prove expects) */
 

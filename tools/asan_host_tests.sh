@@ -21,4 +21,4 @@ PY
 cp -p zklaim_amd/libzkg.so "$OUT/libzkg_release.so"
 trap 'cp -p "$OUT/libzkg_release.so" zklaim_amd/libzkg.so' EXIT
 cp "$OUT/libzkg.so" zklaim_amd/libzkg.so
-LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python3 -m pytest tests/test_zklaim_circuit.py tests/test_verifier.py tests/test_abi.py -x -q
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python3 -m pytest tests/test_zklaim_circuit.py tests/test_verifier.py tests/test_abi.py tests/test_pk_blob_host.py -x -q

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "libzkg.so")
 DECLARED_SYMBOLS = [
     "zkg_init", "zkg_shutdown", "zkg_last_error", "zkg_device_info", "zkg_ntt", "zkg_ntt_dev", "zkg_evaluation_domain_size", "zkg_ntt_domain", "zkg_ntt_domain_dev", "zkg_msm_g1", "zkg_msm_g2",
     "zkg_msm_g1_dev", "zkg_msm_g2_dev", "zkg_msm_g1_windows_dev", "zkg_g1_sum", "zkg_g2_sum", "zkg_g1_fixed_base_dev", "zkg_g2_fixed_base_dev",
-    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_crs_free", "zkg_crs_num_variables", "zkg_groth16_prove", "zkg_groth16_prove_sparse", "zkg_circuit_sparse_witness", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
+    "zkg_crs_upload", "zkg_crs_upload_blob", "zkg_pk_blob_inspect", "zkg_crs_free", "zkg_crs_num_variables", "zkg_groth16_prove", "zkg_groth16_prove_sparse", "zkg_circuit_sparse_witness", "zkg_qap_witness_h", "zkg_prove_stage_ms", "zkg_timing_reset",
     "zkg_timing_dominant_ms", "zkg_zklaim_circuit_new", "zkg_zklaim_witness_new", "zkg_circuit_num_variables", "zkg_circuit_free", "zkg_circuit_r1cs", "zkg_circuit_witness",
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
@@ -133,6 +133,17 @@ def ntt(a, inverse=False, coset=False):
     else:
         _check(lib().zkg_ntt_domain(_p(a), C.c_size_t(n), int(inverse), int(coset)), "zkg_ntt_domain")
     return a.reshape(n, 4)
+
+
+def pk_blob_inspect(blob):
+    """host-only walk of a pk blob (zkg_pk_blob_inspect): dict of its sizes, or ZkgError"""
+    out = np.zeros(8, np.uint64)
+    buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob) if len(blob) else None
+    L = lib()
+    L.zkg_pk_blob_inspect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    _check(L.zkg_pk_blob_inspect(C.cast(buf, C.c_void_p) if buf is not None else None, C.c_size_t(len(blob)), _p(out)), "zkg_pk_blob_inspect")
+    names = ("A_query", "B_values", "H_query", "L_query", "num_inputs", "num_constraints", "terms", "domain_size")
+    return {k: int(v) for k, v in zip(names, out)}
 
 
 def evaluation_domain_size(min_size):

@@ -157,6 +157,36 @@ static void parse_constraint_system(Reader rd, size_t ncons, size_t n_elements, 
     } catch (const std::exception &e) { out.error = std::string("pk blob: ") + e.what(); }
 }
 
+// Where every section of a pk blob lies: the fixed head, the four queries (record runs), the sparse B vector's index list, the constraint
+// system's sizes; rd is left at the first constraint.  Host only (pointer arithmetic and decimal counts), shared by the loader and
+// zkg_pk_blob_inspect.
+struct Sections {
+    const uint8_t *alpha = nullptr, *beta1 = nullptr, *beta2 = nullptr, *delta1 = nullptr, *delta2 = nullptr, *recA = nullptr, *recB = nullptr, *recH = nullptr, *recL = nullptr;
+    size_t nA = 0, nH = 0, nL = 0, primary = 0, auxiliary = 0, ncons = 0;
+    std::vector<uint32_t> idx; DomainShape shape;
+};
+static bool walk_sections(Reader &rd, Sections &s) {
+    s.alpha = rd.take(34); s.beta1 = rd.take(34); s.beta2 = rd.take(66); s.delta1 = rd.take(34); s.delta2 = rd.take(66);
+    if (!rd.ok) { set_error("pk blob: truncated head"); return false; }
+    s.nA = rd.count(34); s.recA = rd.take_records(s.nA, 34);
+    if (!rd.ok || s.nA == 0) { set_error("pk blob: bad A_query"); return false; }
+    // B_query (sparse knowledge commitments: G2 then G1 per value)
+    size_t domain = rd.count(0), nidx = rd.count(2);                      // an index is at least one digit and a newline
+    if (!rd.ok || domain != s.nA || nidx > domain) { set_error("pk blob: bad B_query header"); return false; }
+    s.idx.resize(nidx);
+    for (size_t i = 0; i < nidx; ++i) { size_t v = rd.decimal(); if (!rd.ok || v >= domain) { set_error("pk blob: bad B_query index"); return false; } s.idx[i] = (uint32_t)v; }
+    size_t nval = rd.count(100); s.recB = rd.take_records(nval, 100);
+    if (!rd.ok || nval != nidx) { set_error("pk blob: bad B_query values"); return false; }
+    s.nH = rd.count(34); s.recH = rd.take_records(s.nH, 34);
+    s.nL = rd.ok ? rd.count(34) : 0; s.recL = rd.take_records(s.nL, 34);
+    if (!rd.ok) { set_error("pk blob: bad H/L query"); return false; }
+    s.primary = rd.count(0); s.auxiliary = rd.count(0); s.ncons = rd.count(6);       // a constraint is at least three "0\n" term counts
+    if (!rd.ok || s.primary + s.auxiliary + 1 != s.nA || s.nL != s.auxiliary) { set_error("pk blob: constraint system sizes disagree with the queries"); return false; }
+    // the domain size is not stored in the blob: H_query has m - 1 entries
+    if (!domain_shape_of(s.nH + 1, s.shape)) { set_error("pk blob: H_query length + 1 is neither a power of two nor a step_radix2 size 2^a + 2^b"); return false; }
+    return true;
+}
+
 static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     if (!blob || len < 34 * 3 + 66 * 2) { set_error("zkg_crs_upload_blob: blob too short"); return nullptr; }
     Reader rd{(const uint8_t *)blob, (const uint8_t *)blob + len};
@@ -164,25 +194,13 @@ static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg key blob] %-26s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     // ---- pass 1 (host, pointer arithmetic and the sparse vector's index list): where every section lies
-    const uint8_t *alpha = rd.take(34), *beta1 = rd.take(34), *beta2 = rd.take(66), *delta1 = rd.take(34), *delta2 = rd.take(66);
-    if (!rd.ok) { set_error("pk blob: truncated head"); return nullptr; }
-    size_t nA = rd.count(34); const uint8_t *recA = rd.take_records(nA, 34);
-    if (!rd.ok || nA == 0) { set_error("pk blob: bad A_query"); return nullptr; }
-    // B_query (sparse knowledge commitments: G2 then G1 per value)
-    size_t domain = rd.count(0), nidx = rd.count(2);                      // an index is at least one digit and a newline
-    if (!rd.ok || domain != nA || nidx > domain) { set_error("pk blob: bad B_query header"); return nullptr; }
-    std::vector<uint32_t> idx(nidx);
-    for (size_t i = 0; i < nidx; ++i) { size_t v = rd.decimal(); if (!rd.ok || v >= domain) { set_error("pk blob: bad B_query index"); return nullptr; } idx[i] = (uint32_t)v; }
-    size_t nval = rd.count(100); const uint8_t *recB = rd.take_records(nval, 100);
-    if (!rd.ok || nval != nidx) { set_error("pk blob: bad B_query values"); return nullptr; }
-    size_t nH = rd.count(34); const uint8_t *recH = rd.take_records(nH, 34);
-    size_t nL = rd.ok ? rd.count(34) : 0; const uint8_t *recL = rd.take_records(nL, 34);
-    if (!rd.ok) { set_error("pk blob: bad H/L query"); return nullptr; }
-    size_t primary = rd.count(0), auxiliary = rd.count(0), ncons = rd.count(6);       // a constraint is at least three "0\n" term counts
-    if (!rd.ok || primary + auxiliary + 1 != nA || nL != auxiliary) { set_error("pk blob: constraint system sizes disagree with the queries"); return nullptr; }
-    size_t m_dom = nH + 1;
-    DomainShape shape;                                     // the domain size is not stored in the blob: H_query has m - 1 entries
-    if (!domain_shape_of(m_dom, shape)) { set_error("pk blob: H_query length + 1 is neither a power of two nor a step_radix2 size 2^a + 2^b"); return nullptr; }
+    Sections sec;
+    if (!walk_sections(rd, sec)) return nullptr;
+    const uint8_t *alpha = sec.alpha, *beta1 = sec.beta1, *beta2 = sec.beta2, *delta1 = sec.delta1, *delta2 = sec.delta2;
+    const uint8_t *recA = sec.recA, *recB = sec.recB, *recH = sec.recH, *recL = sec.recL;
+    const size_t nA = sec.nA, domain = sec.nA, nidx = sec.idx.size(), nval = nidx, nH = sec.nH, nL = sec.nL, primary = sec.primary, ncons = sec.ncons;
+    const std::vector<uint32_t> &idx = sec.idx;
+    const DomainShape shape = sec.shape;
     // ---- the constraint system on its own thread ...
     ParsedSystem cs;
     std::thread parser(parse_constraint_system, rd, ncons, nA, std::ref(cs));
@@ -238,6 +256,29 @@ static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     lap("resident key built");
     (void)fail(nullptr);                                                        // releases the staging buffers (no message)
     return crs;
+}
+
+// Host-only walk of a pk blob, the loader's parsing without the GPU: sections, index list, every constraint's terms.  out (optional):
+// A_query entries, B_query values, H_query entries, L_query entries, public inputs, constraints, terms in A + B + C, domain size.
+// ZKG_OK or ZKG_ERROR (zkg_last_error says what was wrong); never reads outside [blob, blob + len).
+static int pk_blob_inspect_impl(const void *blob, size_t len, uint64_t out[8]) {
+    if (!blob) { set_error("zkg_pk_blob_inspect: null blob"); return ZKG_ERROR; }
+    Reader rd{(const uint8_t *)blob, (const uint8_t *)blob + len};
+    Sections sec;
+    if (!walk_sections(rd, sec)) return ZKG_ERROR;
+    ParsedSystem cs;
+    parse_constraint_system(rd, sec.ncons, sec.nA, cs);
+    if (!cs.ok) { set_error(cs.error.empty() ? "pk blob: bad constraint system" : cs.error.c_str()); return ZKG_ERROR; }
+    if (out) {
+        out[0] = sec.nA; out[1] = sec.idx.size(); out[2] = sec.nH; out[3] = sec.nL; out[4] = sec.primary; out[5] = sec.ncons;
+        out[6] = cs.col[0].size() + cs.col[1].size() + cs.col[2].size(); out[7] = sec.shape.m;
+    }
+    return ZKG_OK;
+}
+extern "C" int zkg_pk_blob_inspect(const void *blob, size_t len, uint64_t out[8]) {
+    try { return pk_blob_inspect_impl(blob, len, out); }
+    catch (const std::exception &e) { set_error(std::string("zkg_pk_blob_inspect: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { set_error("zkg_pk_blob_inspect: unexpected exception"); return ZKG_ERROR; }
 }
 
 // Nothing may propagate through the C boundary: allocation failures on hostile sizes end up here as an error return.
