@@ -548,10 +548,64 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     int lg_count = 0; while (((size_t)1 << (lg_count + 1)) <= count) ++lg_count;
     crs->c_w = crs->c_w_forced ? crs->c_w_forced : std::min(14, std::max(10, lg_count + 2));
     msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w);
-    // the G2 table on the B_g2 job's stream (idle as well), beside the three G1 tables: a few thousand points per launch are latency chains
     DevBuf stage, stage2;
-    if (stage.reserve(count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
+    if (stage.reserve(3 * count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
     const uint32_t *d_idx = T.idx.as<uint32_t>();
+    static const size_t host_limit = getenv("ZKG_SUBSET_HOST_LIMIT") ? (size_t)atoi(getenv("ZKG_SUBSET_HOST_LIMIT")) : 320;   // tuning aid
+    if (count <= host_limit) {
+        // A small subset (a credential of up to ~10 payloads): on the GPU each table is a chain of 254 doublings and W / 4 inversions per lane
+        // whatever the count — 10 ms for 22 points; the host pool walks the same chains at 0.08 ms per G1 point (0.25 ms per G2 point), a
+        // task per (table, point), and uploads the finished levels.
+        G1Affine *d1 = stage.as<G1Affine>();
+        int rc = gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, d1, s) || gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, d1 + count, s) ||
+                 gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), d1 + 2 * count, s) ||
+                 gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage2.as<G2Affine>(), s);
+        std::vector<G1Affine> p1(3 * count); std::vector<G2Affine> p2(count);
+        const bool got = !rc && hip_ok(hipMemcpyAsync(p1.data(), d1, 3 * count * sizeof(G1Affine), hipMemcpyDeviceToHost, s), "D2H", __FILE__, __LINE__) &&
+                         hip_ok(hipMemcpyAsync(p2.data(), stage2.p, count * sizeof(G2Affine), hipMemcpyDeviceToHost, s), "D2H", __FILE__, __LINE__) &&
+                         hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);
+        stage.release(); stage2.release();
+        if (!got) { T.count = 0; return ZKG_ERROR; }
+        const int c = crs->c_w, W = (254 + c) / c;                               // = (SCALAR_BITS + c - 1) / c of window_table_build
+        std::vector<G1Affine> t1((size_t)3 * W * count); std::vector<G2Affine> t2((size_t)W * count);
+        auto levels = [&](auto base, auto *out /* level w of this point at out[w * count] */) {
+            typedef decltype(base.x) F;
+            if (base.is_inf()) { for (int w = 0; w < W; ++w) out[(size_t)w * count] = base; return; }
+            std::vector<XYZZ<F>> lv(W);
+            XYZZ<F> p = XYZZ<F>::from_affine(base);
+            for (int w = 1; w < W; ++w) { for (int k = 0; k < c; ++k) p = p.dbl(); lv[w] = p; }
+            std::vector<F> pre(W); F run = F::one();
+            for (int w = 1; w < W; ++w) { pre[w] = run; if (!lv[w].is_inf()) run = run * lv[w].zzz; }
+            F inv = run.inverse();
+            out[0] = base;
+            for (int w = W - 1; w >= 1; --w) {
+                if (lv[w].is_inf()) { out[(size_t)w * count] = decltype(base)::inf(); continue; }
+                F zi = inv * pre[w]; inv = inv * lv[w].zzz;
+                F z1 = zi * lv[w].zz, zi2 = z1.sqr();
+                out[(size_t)w * count] = {lv[w].x * zi2, lv[w].y * zi};
+            }
+        };
+        host_parallel_for_wait((int)(4 * count), [&](int task) {
+            const size_t tb = (size_t)task / count, i = (size_t)task % count;
+            if (tb < 3) levels(p1[tb * count + i], &t1[tb * (size_t)W * count + i]); else levels(p2[i], &t2[i]);
+        });
+        WindowTable *g1t[3] = {&T.A, &T.B1, &T.L};
+        bool up = true;
+        for (int tb = 0; tb < 3 && up; ++tb) {
+            WindowTable &t = *g1t[tb]; t.n = count; t.c = c; t.W = W; t.g2 = false;
+            up = t.buf.reserve((size_t)W * count * sizeof(G1Affine)) == 0 &&
+                 hip_ok(hipMemcpyAsync(t.buf.p, &t1[tb * (size_t)W * count], (size_t)W * count * sizeof(G1Affine), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__);
+        }
+        T.B2.n = count; T.B2.c = c; T.B2.W = W; T.B2.g2 = true;
+        up = up && T.B2.buf.reserve((size_t)W * count * sizeof(G2Affine)) == 0 &&
+             hip_ok(hipMemcpyAsync(T.B2.buf.p, t2.data(), (size_t)W * count * sizeof(G2Affine), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__);
+        up = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__) && up;          // (host vectors go out of scope)
+        if (!up) { T.count = 0; return ZKG_ERROR; }
+        T.count = count; ++T.rebuilds;
+        if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u, levels on the host)\n", count, n1, T.rebuilds);
+        return ZKG_OK;
+    }
+    // the G2 table on the B_g2 job's stream (idle as well), beside the three G1 tables: a few thousand points per launch are latency chains
     hipStream_t s2 = msm_job_stream(S.job_w2);
     bool ok = hip_ok(hipEventRecord(S.ev[11], s), "event", __FILE__, __LINE__) && hip_ok(hipStreamWaitEvent(s2, S.ev[11], 0), "wait", __FILE__, __LINE__);   // idx is up
     int rc = !ok || gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage2.as<G2Affine>(), s2) || window_table_build_g2(T.B2, stage2.as<G2Affine>(), count, crs->c_w, s2) ||
