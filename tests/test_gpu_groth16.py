@@ -250,7 +250,7 @@ def test_witness_tables_grow_with_the_witnesses_seen(zkg, oracle):
         return vals
 
     first = list(range(100, 400, 3)); second = list(range(1000, 1900, 7))
-    shapes = [[], first, second, first + second, [0, 1, n - 1], first]
+    shapes = [[], first, second, first + second, [0, 1, n - 1], first, list(range(0, 2400, 2)), second]     # (up to 1024 elements the levels are built on the host, above on the GPU)
     n_, l, A, B, C, _ = _trivial_system([0] * n)
     keep = []
     ocs = oracle.make_r1cs(n, l, A, B, C, keep)

@@ -551,11 +551,12 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     DevBuf stage, stage2;
     if (stage.reserve(3 * count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
     const uint32_t *d_idx = T.idx.as<uint32_t>();
-    static const size_t host_limit = getenv("ZKG_SUBSET_HOST_LIMIT") ? (size_t)atoi(getenv("ZKG_SUBSET_HOST_LIMIT")) : 320;   // tuning aid
+    static const size_t host_limit = getenv("ZKG_SUBSET_HOST_LIMIT") ? (size_t)atoi(getenv("ZKG_SUBSET_HOST_LIMIT")) : 1024;   // tuning aid
     if (count <= host_limit) {
-        // A small subset (a credential of up to ~10 payloads): on the GPU each table is a chain of 254 doublings and W / 4 inversions per lane
-        // whatever the count — 10 ms for 22 points; the host pool walks the same chains at 0.08 ms per G1 point (0.25 ms per G2 point), a
-        // task per (table, point), and uploads the finished levels.
+        // A small subset (every credential size zklaim's benchmark covers): on the GPU each table is a chain of 254 doublings and W / 4
+        // inversions per lane whatever the count — 10 ms for 22 points; the host pool walks the same chains at 0.08 ms per G1 point (0.25 ms
+        // per G2 point), a task per (table, point), and uploads the finished levels.  Same-box A/B: 8 ms less at 12 payloads (324
+        // elements), 6 ms less at 20 (552); the costs meet around a thousand elements.
         G1Affine *d1 = stage.as<G1Affine>();
         int rc = gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, d1, s) || gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, d1 + count, s) ||
                  gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), d1 + 2 * count, s) ||
