@@ -229,49 +229,73 @@ inline Fq12 mul_by_line2(const Fq12 &f, const Fq2 &a, const Fq2 &b, const Fq2 &c
 //   doubling (slope 3X^2 / 2YZ):   l * 2YZ  =  2YZ yP  -  3X^2 xP w  +  (Y^2 - 3b' Z^2) w^3      [3X^3 - 2Y^2 Z = Z (Y^2 - 3b' Z^2) on the curve]
 //   adding Q (slope theta / mu, theta = Y - yQ Z, mu = X - xQ Z):   l * mu  =  mu yP  -  theta xP w  +  (theta xQ - mu yQ) w^3
 // and the point updates are the same chord / tangent rules with denominators cleared.
-inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n) {
-    const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;   // 6z+2 = 29793968203157093288 (65 bits)
-    static const Fq2 b3 = fq2(9, 0) * fq2_inverse_host(xi());       // 3 b'
-    struct Proj { Fq2 X, Y, Z; };
-    Fq12 f = Fq12::one();
-    std::vector<Proj> T(n);
-    for (int j = 0; j < n; ++j) T[j] = {Q[j].x, Q[j].y, Fq2::one()};
-    auto dbl_step = [&]() {
-        f = f.sqr();
-        for (int j = 0; j < n; ++j) {
-            Proj &t = T[j];
-            Fq2 B = t.Y.sqr(), C = t.Z.sqr(), E = C * b3, F = E.dbl() + E, H = (t.Y + t.Z).sqr() - B - C, J = t.X.sqr();
-            f = mul_by_line2(f, scale(H, P[j].y), scale(J.dbl() + J, P[j].x).neg(), B - E);
-            Fq2 E2 = E.sqr(), E4 = E2.dbl().dbl();
-            Fq2 X3 = ((t.X * t.Y) * (B - F)).dbl(), Y3 = (B + F).sqr() - (E4.dbl() + E4), Z3 = (B * H).dbl().dbl();
-            t = {X3, Y3, Z3};
-        }
-    };
-    auto add_step = [&](const std::vector<G2Affine> &R_) {
-        for (int j = 0; j < n; ++j) {
-            Proj &t = T[j];
-            Fq2 theta = t.Y - R_[j].y * t.Z, mu = t.X - R_[j].x * t.Z;
-            f = mul_by_line2(f, scale(mu, P[j].y), scale(theta, P[j].x).neg(), theta * R_[j].x - mu * R_[j].y);
-            Fq2 C = theta.sqr(), D = mu.sqr(), E = mu * D, F = t.Z * C, G = t.X * D, H = E + F - G.dbl();
-            t = {mu * H, theta * (G - H) - E * t.Y, t.Z * E};
-        }
-    };
-    std::vector<G2Affine> Q0(Q, Q + n);
-    for (int i = 63; i >= 0; --i) {                          // bit 64 is the leading one
-        dbl_step();
-        if ((S >> i) & 1) add_step(Q0);
+// One step's line, before the G1 point enters it: the step multiplies f by  a yP  -  b xP w  +  c w^3.
+struct LineCoeff { Fq2 a, b, c; };
+// The running point of one pairing's Miller loop and the two kinds of step.
+struct LineWalker {
+    Fq2 X, Y, Z;
+    explicit LineWalker(const G2Affine &Q) : X(Q.x), Y(Q.y), Z(Fq2::one()) {}
+    LineCoeff dbl() {
+        static const Fq2 b3 = fq2(9, 0) * fq2_inverse_host(xi());       // 3 b'
+        Fq2 B = Y.sqr(), C = Z.sqr(), E = C * b3, F = E.dbl() + E, H = (Y + Z).sqr() - B - C, J = X.sqr();
+        LineCoeff l = {H, J.dbl() + J, B - E};
+        Fq2 E2 = E.sqr(), E4 = E2.dbl().dbl();
+        Fq2 X3 = ((X * Y) * (B - F)).dbl(), Y3 = (B + F).sqr() - (E4.dbl() + E4), Z3 = (B * H).dbl().dbl();
+        X = X3; Y = Y3; Z = Z3;
+        return l;
     }
-    // gamma = xi^((q-1)/6): pi(Q) = (conj(x) gamma^2, conj(y) gamma^3); pi^2(Q) = (x N^2, y N^3) with N = gamma conj(gamma) in Fq
+    LineCoeff add(const G2Affine &R) {
+        Fq2 theta = Y - R.y * Z, mu = X - R.x * Z;
+        LineCoeff l = {mu, theta, theta * R.x - mu * R.y};
+        Fq2 C = theta.sqr(), D = mu.sqr(), E = mu * D, F = Z * C, G = X * D, H = E + F - G.dbl();
+        Fq2 X3 = mu * H, Y3 = theta * (G - H) - E * Y, Z3 = Z * E;
+        X = X3; Y = Y3; Z = Z3;
+        return l;
+    }
+};
+// The step schedule of the optimal ate loop for 6z + 2 = 29793968203157093288 (65 bits; bit 64 is the leading one): f(step_is_doubling,
+// which_addend) is called for 64 doublings, an addition of Q after each doubling whose bit is set, then the additions of pi(Q) and -pi^2(Q).
+template <class Fn> inline void miller_schedule(Fn step) {
+    const unsigned __int128 S = ((unsigned __int128)1 << 64) + 11347224129447541672ull;
+    for (int i = 63; i >= 0; --i) { step(true, 0); if ((S >> i) & 1) step(false, 0); }
+    step(false, 1); step(false, 2);
+}
+// Q, pi(Q), -pi^2(Q):  gamma = xi^((q-1)/6): pi(Q) = (conj(x) gamma^2, conj(y) gamma^3); pi^2(Q) = (x N^2, y N^3) with N = gamma conj(gamma) in Fq
+inline void miller_addends(const G2Affine &Q, G2Affine out[3]) {
     static const Fq2 g1 = gamma1();
     static const Fq2 g2 = g1.sqr(), g3 = g2 * g1, n1 = g1 * conj(g1), n2 = n1.sqr(), n3 = n2 * n1;
-    std::vector<G2Affine> Q1(n), Q2(n);
+    out[0] = Q;
+    out[1] = frobenius_twist(Q, g2, g3, true);
+    G2Affine t = frobenius_twist(Q, n2, n3, false);
+    out[2] = {t.x, t.y.neg()};
+}
+// every line of the loop of a fixed Q, in schedule order: what a verification key's gamma_g2 and delta_g2 contribute to every verification
+inline std::vector<LineCoeff> miller_lines(const G2Affine &Q) {
+    std::vector<LineCoeff> lines; lines.reserve(96);
+    G2Affine addend[3]; miller_addends(Q, addend);
+    LineWalker t(Q);
+    miller_schedule([&](bool doubling, int which) { lines.push_back(doubling ? t.dbl() : t.add(addend[which])); });
+    return lines;
+}
+// prepared[j] (optional, per pair): the lines of Q[j] computed earlier by miller_lines — Q[j] itself is not read then
+inline Fq12 multi_miller_loop(const G1Affine *P, const G2Affine *Q, int n, const std::vector<LineCoeff> *const *prepared = nullptr) {
+    Fq12 f = Fq12::one();
+    std::vector<LineWalker> T; std::vector<G2Affine> addend((size_t)3 * n);
+    T.reserve(n);
     for (int j = 0; j < n; ++j) {
-        Q1[j] = frobenius_twist(Q[j], g2, g3, true);
-        G2Affine t = frobenius_twist(Q[j], n2, n3, false);
-        Q2[j] = {t.x, t.y.neg()};
+        const bool live = !(prepared && prepared[j]);
+        T.emplace_back(live ? Q[j] : G2Affine{Fq2::one(), Fq2::one()});
+        if (live) miller_addends(Q[j], &addend[(size_t)3 * j]);
     }
-    add_step(Q1);
-    add_step(Q2);
+    size_t pos = 0;
+    miller_schedule([&](bool doubling, int which) {
+        if (doubling) f = f.sqr();
+        for (int j = 0; j < n; ++j) {
+            const LineCoeff l = (prepared && prepared[j]) ? (*prepared[j])[pos] : (doubling ? T[j].dbl() : T[j].add(addend[(size_t)3 * j + which]));
+            f = mul_by_line2(f, scale(l.a, P[j].y), scale(l.b, P[j].x).neg(), l.c);
+        }
+        ++pos;
+    });
     return f;
 }
 

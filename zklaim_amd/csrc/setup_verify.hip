@@ -13,6 +13,8 @@
 #include "common.hpp"
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -283,41 +285,85 @@ size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap) {
 
 // r1cs_gg_ppzksnark_verifier_strong_IC: 0 = proof valid, 1 = invalid (libsnark_verify returns !valid, libsnark_wrapper.cpp:269),
 // 2 = malformed key / proof.  primary_input: n_inputs x 4 limbs, Montgomery Fr.
-static int groth16_verify_impl(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
-    if (!vk_blob || !proof || (n_inputs && !primary_input)) { set_error("zkg_groth16_verify: null argument"); return 2; }
+// What a verification key contributes to every verification, computed once per key: its points decompressed (one square root each —
+// l + 3 of them) and every line of the Miller loops of gamma_g2 and delta_g2 (libsnark's r1cs_gg_ppzksnark_processed_verification_key;
+// the reference's libsnark_verify re-parses and re-processes ctx->vk on every call, libsnark_wrapper.cpp:252-276).  Kept per vk blob —
+// found by a 64-bit digest, confirmed byte for byte — for the last few keys.
+struct PreparedVk {
+    std::vector<uint8_t> blob;
+    Fq12 alpha_beta; G2Affine gamma_g2, delta_g2; G1Affine ic0; size_t domain = 0;
+    std::vector<size_t> idx; std::vector<G1Affine> ic;                          // gamma_ABC: indices and decompressed values
+    std::vector<pairing::LineCoeff> gamma_lines, delta_lines;                   // empty when the point is infinity
+};
+static int prepare_vk(const uint8_t *vk_blob, size_t vk_len, PreparedVk &v) {   // 0, or 2 = malformed (message set)
     ser::Reader rd{vk_blob, vk_blob + vk_len};
     const uint8_t *gt = rd.take(384), *pg = rd.take(66), *pd = rd.take(66), *p0 = rd.take(34);
     if (!rd.ok) { set_error("vk blob truncated"); return 2; }
-    Fq12 alpha_beta; ser::get_fq12(gt, alpha_beta);
-    G2Affine gamma_g2, delta_g2; G1Affine ic0;
-    if (!ser::get_g2(pg, gamma_g2) || !ser::get_g2(pd, delta_g2) || !ser::get_g1(p0, ic0)) { set_error("vk blob: bad point"); return 2; }
+    ser::get_fq12(gt, v.alpha_beta);
+    if (!ser::get_g2(pg, v.gamma_g2) || !ser::get_g2(pd, v.delta_g2) || !ser::get_g1(p0, v.ic0)) { set_error("vk blob: bad point"); return 2; }
     size_t domain = rd.dec(), nidx = rd.dec();
     // counts are bounded by the bytes that can still follow (an index takes >= 2 bytes, a value 34) before anything is sized by them
     if (!rd.ok || nidx > domain || nidx > (size_t)(rd.end - rd.p) / 2) { set_error("vk blob: bad gamma_ABC header"); return 2; }
-    std::vector<size_t> idx(nidx);
-    for (auto &i : idx) { i = rd.dec(); if (!rd.ok || i >= domain) { set_error("vk blob: bad index"); return 2; } }
+    v.domain = domain; v.idx.resize(nidx);
+    for (auto &i : v.idx) { i = rd.dec(); if (!rd.ok || i >= domain) { set_error("vk blob: bad index"); return 2; } }
     size_t nval = rd.dec();
     if (!rd.ok || nval != nidx || nval > (size_t)(rd.end - rd.p) / 34) { set_error("vk blob: bad gamma_ABC values"); return 2; }
     const uint8_t *vals = rd.take(nval * 34);
     if (!rd.ok) { set_error("vk blob: truncated gamma_ABC values"); return 2; }
-    if (domain != n_inputs) return 1;                                           // strong input consistency: sizes must agree
+    v.ic.resize(nidx);
+    std::vector<char> bad(nidx, 0);
+    host_parallel_for((int)nidx, [&](int k) { if (!ser::get_g1(vals + 34 * (size_t)k, v.ic[k])) bad[k] = 1; });
+    for (char b : bad) if (b) { set_error("vk blob: bad gamma_ABC point"); return 2; }
+    if (!v.gamma_g2.is_inf()) v.gamma_lines = pairing::miller_lines(v.gamma_g2);
+    if (!v.delta_g2.is_inf()) v.delta_lines = pairing::miller_lines(v.delta_g2);
+    v.blob.assign(vk_blob, vk_blob + vk_len);
+    return 0;
+}
+static std::mutex g_vk_mu;
+static std::map<uint64_t, std::shared_ptr<const PreparedVk>> g_vk_cache;
+static uint64_t vk_digest(const uint8_t *p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ n; size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    for (; i < n; ++i) { h = (h ^ p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    return h;
+}
+static std::shared_ptr<const PreparedVk> prepared_vk(const uint8_t *vk_blob, size_t vk_len, int &rc) {
+    const uint64_t key = vk_digest(vk_blob, vk_len);
+    {
+        std::lock_guard<std::mutex> lk(g_vk_mu);
+        auto it = g_vk_cache.find(key);
+        if (it != g_vk_cache.end() && it->second->blob.size() == vk_len && memcmp(it->second->blob.data(), vk_blob, vk_len) == 0) { rc = 0; return it->second; }
+    }
+    auto v = std::make_shared<PreparedVk>();
+    rc = prepare_vk(vk_blob, vk_len, *v);
+    if (rc) return nullptr;
+    std::lock_guard<std::mutex> lk(g_vk_mu);
+    if (g_vk_cache.size() >= 8) g_vk_cache.clear();
+    g_vk_cache[key] = v;
+    return v;
+}
+
+static int groth16_verify_impl(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
+    if (!vk_blob || !proof || (n_inputs && !primary_input)) { set_error("zkg_groth16_verify: null argument"); return 2; }
+    int rc = 0;
+    const std::shared_ptr<const PreparedVk> vk = prepared_vk(vk_blob, vk_len, rc);
+    if (!vk) return rc;
+    const size_t nidx = vk->idx.size();
+    if (vk->domain != n_inputs) return 1;                                       // strong input consistency: sizes must agree
     if (proof_len != ZKG_PROOF_BYTES) return 1;
     G1Affine pA, pC; G2Affine pB;
     if (!ser::get_g1(proof, pA) || !ser::get_g2(proof + 34, pB) || !ser::get_g1(proof + 100, pC)) return 1;     // is_well_formed
     // acc = IC_0 + sum_i input_i * IC_{i+1}
-    G1 acc = G1::from_affine(ic0);
+    G1 acc = G1::from_affine(vk->ic0);
     {   // sum_i input_i * IC_{i+1} in up to 16 chunks on the host pool.  A chunk shares its doublings (Straus, one bit at a time: 254 doublings
         // and on average 127 mixed additions per point instead of a double-and-add per point): 0.67 -> 0.3 ms at 20 payloads' 102 inputs.
         const int chunks = (int)std::min<size_t>(16, nidx);
-        std::vector<G1> part(std::max(chunks, 1), G1::inf()); std::vector<char> bad(std::max(chunks, 1), 0);
+        std::vector<G1> part(std::max(chunks, 1), G1::inf());
         host_parallel_for(chunks, [&](int c) {
             const size_t lo = nidx * (size_t)c / chunks, hi = nidx * (size_t)(c + 1) / chunks, cnt = hi - lo;
-            std::vector<G1Affine> pt(cnt); std::vector<uint32_t> e(8 * cnt);
-            for (size_t k = lo; k < hi; ++k) {
-                if (!ser::get_g1(vals + 34 * k, pt[k - lo])) { bad[c] = 1; return; }
-                Fr x; memcpy(x.v, primary_input + 4 * idx[k], 32);
-                fr_limbs(x, &e[8 * (k - lo)]);
-            }
+            std::vector<uint32_t> e(8 * cnt);
+            for (size_t k = lo; k < hi; ++k) { Fr x; memcpy(x.v, primary_input + 4 * vk->idx[k], 32); fr_limbs(x, &e[8 * (k - lo)]); }
+            const G1Affine *pt = vk->ic.data() + lo;
             G1 a = G1::inf();
             for (int bit = 255; bit >= 0; --bit) {
                 a = a.dbl();
@@ -325,15 +371,16 @@ static int groth16_verify_impl(const uint8_t *vk_blob, size_t vk_len, const uint
             }
             part[c] = a;
         });
-        for (int c = 0; c < chunks; ++c) { if (bad[c]) { set_error("vk blob: bad gamma_ABC point"); return 2; } acc.add(part[c]); }
+        for (int c = 0; c < chunks; ++c) acc.add(part[c]);
     }
     // e(A, B) == e(alpha, beta) * e(acc, gamma) * e(C, delta)   <=>   FE( ML(A,B) * ML(-acc, gamma) * ML(-C, delta) ) == alpha_beta
+    // (three loops in lock-step; the lines of gamma and delta come from the prepared key, only B's are computed here)
     G1Affine accA = acc.to_affine();
-    std::vector<G1Affine> Ps; std::vector<G2Affine> Qs;
-    auto ml = [&](const G1Affine &P, const G2Affine &Q) { if (!P.is_inf() && !Q.is_inf()) { Ps.push_back(P); Qs.push_back(Q); } };
-    ml(pA, pB); ml(accA.neg(), gamma_g2); ml(pC.neg(), delta_g2);
-    Fq12 f = Ps.empty() ? Fq12::one() : pairing::multi_miller_loop(Ps.data(), Qs.data(), (int)Ps.size());   // three loops in lock-step
-    return pairing::final_exponentiation(f) == alpha_beta ? 0 : 1;
+    std::vector<G1Affine> Ps; std::vector<G2Affine> Qs; std::vector<const std::vector<pairing::LineCoeff> *> prep;
+    auto ml = [&](const G1Affine &P, const G2Affine &Q, const std::vector<pairing::LineCoeff> *lines) { if (!P.is_inf() && !Q.is_inf()) { Ps.push_back(P); Qs.push_back(Q); prep.push_back(lines); } };
+    ml(pA, pB, nullptr); ml(accA.neg(), vk->gamma_g2, &vk->gamma_lines); ml(pC.neg(), vk->delta_g2, &vk->delta_lines);
+    Fq12 f = Ps.empty() ? Fq12::one() : pairing::multi_miller_loop(Ps.data(), Qs.data(), (int)Ps.size(), prep.data());
+    return pairing::final_exponentiation(f) == vk->alpha_beta ? 0 : 1;
 }
 
 int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len) {
@@ -353,7 +400,7 @@ int zkg_pairing_probe(const uint64_t a[4], const uint64_t b[4], uint8_t out[384]
 
 // test hook: 0 when (1) x -> x^(q^k) by coefficient maps equals square-and-multiply by q^k (k = 1, 2, 3) and (2) the last chunk of the
 // final exponentiation equals square-and-multiply by the integer `e` (nlimbs x u32, little-endian) and (3) the projective and the
-// affine Miller loops give the same reduced pairing products; bit flags otherwise
+// affine Miller loops give the same reduced pairing products and (4) prepared lines give the same Miller value; bit flags otherwise
 int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
     uint32_t k3[8] = {3}, k5[8] = {5};
     G1Affine P = G1::from_affine(g1_generator()).mul(k3, 8).to_affine();
@@ -371,6 +418,11 @@ int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
         for (int j = 0; j < 3; ++j) { Ps[j] = G1::from_affine(g1_generator()).mul(k[j], 8).to_affine(); Qs[j] = G2::from_affine(g2_generator()).mul(k[3 + j], 8).to_affine(); }
         for (int n = 1; n <= 3; ++n)
             if (!(pairing::final_exponentiation(pairing::multi_miller_loop(Ps, Qs, n)) == pairing::final_exponentiation(pairing::multi_miller_loop_affine(Ps, Qs, n)))) bad |= 32;
+        // lines prepared ahead for two of the three pairs (a verification key's gamma and delta): the very same Miller value
+        std::vector<pairing::LineCoeff> l1 = pairing::miller_lines(Qs[1]), l2 = pairing::miller_lines(Qs[2]);
+        const std::vector<pairing::LineCoeff> *prep[3] = {nullptr, &l1, &l2};
+        G2Affine unused[3] = {Qs[0], G2Affine::inf(), G2Affine::inf()};
+        if (!(pairing::multi_miller_loop(Ps, unused, 3, prep) == pairing::multi_miller_loop(Ps, Qs, 3))) bad |= 64;
     }
     return bad;
 }
