@@ -911,7 +911,9 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
     uint32_t cbits = 6;
     static const uint32_t bin_avg = getenv("ZKG_RX_AVG") ? (uint32_t)atoi(getenv("ZKG_RX_AVG")) : RX_BIN_AVG;     // tuning aid
     while (cbits < RX_MAX_CBITS && cbits + 1 < g.c - 1 && (n >> cbits) > bin_avg) ++cbits;  // bins average <= RX_BIN_AVG entries where possible, fbits >= 2
-    const bool two_pass = !radix_off && !job->one_pass_sort && g.c >= 12 && n >= 4096 && (n >> cbits) <= RX_FINE_MAX && n <= ((size_t)1 << (31 - (g.c - 1 - cbits)));
+    // (below ~2^15.5 points the one-pass sort's six small launches beat the two-pass sort's eleven: a one-payload proof's H query, 2^15 - 1
+    //  points, 0.657 -> 0.603 ms; equal at 2^16, the two-pass sort 5 % ahead at 2^17)
+    const bool two_pass = !radix_off && !job->one_pass_sort && g.c >= 12 && n >= 49152 && (n >> cbits) <= RX_FINE_MAX && n <= ((size_t)1 << (31 - (g.c - 1 - cbits)));
     if (two_pass) {
         // two-pass sort: 2^cbits coarse bins per window, then the remaining fbits inside LDS
         const uint32_t fbits = g.c - 1 - cbits, CB = 1u << cbits, nbins = g.W * CB, S1 = (uint32_t)((n + RX_SLICE - 1) / RX_SLICE);
