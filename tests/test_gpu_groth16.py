@@ -270,6 +270,53 @@ def test_witness_tables_grow_with_the_witnesses_seen(zkg, oracle):
     crs.free(); crs_blob.free()
 
 
+def test_concurrent_callers_extend_the_witness_tables(zkg, oracle):
+    """Three callers on ONE fresh key (its prover slots), each walking witnesses whose non-bit positions differ from the others': the
+    shared witness tables get extended while other proofs are in flight (a proof that must extend them waits for the others and holds
+    new ones back, prover.hip zkg_crs).  Every proof's bytes against the oracle's."""
+    import threading
+    rng = np.random.default_rng(31)
+    n = 1200
+    n_, l, A, B, C, _ = _trivial_system([0] * n)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x81))
+    opk = oracle.make_pk(ocs, crs_arrays)
+    m = crs_arrays["m"]
+    shapes = [list(range(a, b, st)) for a, b, st in ((0, 90, 3), (100, 400, 5), (400, 1200, 11), (3, 1100, 13), (50, 60, 1), (600, 1199, 2))]
+    cases = []
+    for j, shape in enumerate(shapes):
+        vals = [int(x) for x in rng.integers(0, 2, n)]
+        for p_ in shape:
+            vals[p_] = int.from_bytes(rng.bytes(31), "little") % (R - 2) + 2
+        w = arr(vals, R); rs = random_fr_canonical(2, 0x82 + j)
+        rc_o, proof_o = oracle.groth16_prove(opk, w, rs[0], rs[1])
+        assert rc_o == 0
+        cases.append((w, rs, proof_o))
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, (m - 1).bit_length(), keep, domain_size=m))
+    errors = []
+
+    def caller(order):
+        try:
+            for rep in range(3):
+                for j in order:
+                    w, rs, expect = cases[j]
+                    rc, proof = crs.prove(w, rs[0], rs[1])
+                    if rc != 0 or proof != expect:
+                        errors.append((j, rc))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=caller, args=(o,)) for o in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0], [2, 4, 0, 5, 1, 3])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:5]
+    crs.free()
+
+
 def test_concurrent_callers_get_the_serial_proofs(zkg, oracle):
     """Re-entrancy of the boundary (SURVEY §8(b) threading: the reference seam is not re-entrant, this one is).  Two resident keys of
     different domain sizes, four host threads proving on them at once (two per key: callers of one key queue on its slot, the two

@@ -1,5 +1,5 @@
-"""Proofs per second with several callers: T host threads prove the same k-payload credential, each on a resident copy of the key
-(argv: k, threads, proofs per thread).  One caller = the latency figure bench.py reports; more callers show what the chip still
+"""Proofs per second with several callers: T host threads prove the same k-payload credential on ONE resident key (the key's prover
+slots; SHARED_KEY=0: each on a resident copy of the key) (argv: k, threads, proofs per thread).  One caller = the latency figure bench.py reports; more callers show what the chip still
 has to give when a proof's latency-bound phases run under another proof's kernels."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,9 @@ ck = zkg.ZklaimCircuit(zkg.make_ctx(pls, keep))
 tags, fidx, fvals = ck.sparse_witness()
 kp = zkg.Keypair(ck.r1cs, bench.splitmix_fr(5, 77))
 rs = bench.splitmix_fr(2, 9)
+shared = os.environ.get("SHARED_KEY", "1") != "0"        # one resident key for all callers (its prover slots) or a copy per caller
 for nthreads in range(1, T + 1):
-    crss = [zkg.Crs(kp.pk) for _ in range(nthreads)]
+    crss = [zkg.Crs(kp.pk)] * nthreads if shared else [zkg.Crs(kp.pk) for _ in range(nthreads)]
     expect = crss[0].prove_sparse(tags, fidx, fvals, rs[0], rs[1])
     for c in crss:
         assert c.prove_sparse(tags, fidx, fvals, rs[0], rs[1]) == expect
@@ -33,4 +34,4 @@ for nthreads in range(1, T + 1):
     dt = time.perf_counter() - t0
     assert not bad
     print(f"k={k} callers={nthreads}: {nthreads * reps / dt:.1f} proofs/s ({dt / reps * 1e3:.3f} ms per proof per caller)", flush=True)
-    for c in crss: c.free()
+    for c in set(crss): c.free()

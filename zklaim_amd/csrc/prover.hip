@@ -33,8 +33,8 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 
 // Everything one proof in flight needs on top of the shared key: its [1 | w], the three evaluation vectors, the transform
 // scratch, a stream for the mat-vec / NTT pipeline, three MSM jobs (stream + workspace + pinned landing zone each) and the
-// events that order them.  One per key: keeping two proofs in flight (the host tail of proof i under the GPU work of proof
-// i+1) was built and measured in round 1 — slower, because one proof's concurrent MSMs already fill the chip.
+// events that order them.  Up to three per key for small domains, created when callers overlap (see zkg_crs): a large proof's
+// concurrent MSMs already fill the chip, a small one leaves room.
 // One persistent helper thread per prover slot: it queues the witness streams' work while the calling thread queues the critical path, and
 // later computes one of the two variable-base products of the assembly.  (std::async spawned a thread for each: 30-50 us apiece on every
 // proof, and the occasional multi-millisecond outlier when the spawn was slow.)
@@ -137,9 +137,16 @@ struct zkg_crs {
     zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
     zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
-    ProverSlot slot[1];
+    // Prover slots.  A lone caller only ever uses slot 0 (created with the key).  When callers arrive on several threads, a second and a
+    // third slot are created on first need: from 8 payloads up one proof fills the chip and a second in flight adds 4 %, but a one-payload
+    // proof is latency chains and three in flight give 1.6x the proofs per second (tools/prove_throughput.py).  The witness tables are
+    // shared: a proof that has to extend them waits, holding its slot, until every other proof in flight has either finished or is waiting
+    // for the same reason, and no new proof starts meanwhile (`extending`, `waiting_ext`).
+    static constexpr int MAX_SLOTS = 3;
+    ProverSlot slot[MAX_SLOTS];
     float stage_ms[8] = {0};
-    std::mutex mu;
+    std::mutex mu; std::condition_variable cv;
+    bool busy[MAX_SLOTS] = {false, false, false}; int leases = 0, waiting_ext = 0; bool extending = false;
 };
 
 namespace zk {
@@ -491,11 +498,53 @@ void zkg_crs_free(zkg_crs *crs) {
 
 uint32_t zkg_crs_num_variables(const zkg_crs *crs) { return crs ? crs->n : 0; }
 
+// A caller's hold on one prover slot of a key (see zkg_crs): blocks until a slot is free and no table extension is pending.
+struct SlotLease {
+    zkg_crs *crs; int i = -1;
+    explicit SlotLease(zkg_crs *c) : crs(c) {
+        // how many proofs of this key may be in flight: measured proofs per second with 1 / 2 / 3 callers — one payload (m = 2^15) 1069 /
+        // 1142 / 1706, eight payloads (2^18) 609 / 698 / 576, 37 payloads (2^20) 250 / 247.  ZKG_PROVER_SLOTS caps it (1 = callers queue).
+        static const int env_slots = [] { const char *e = getenv("ZKG_PROVER_SLOTS"); int v = e ? atoi(e) : zkg_crs::MAX_SLOTS; return v < 1 ? 1 : v > zkg_crs::MAX_SLOTS ? zkg_crs::MAX_SLOTS : v; }();
+        const int max_slots = std::min(env_slots, c->m < ((size_t)1 << 18) ? 3 : c->m < ((size_t)1 << 19) ? 2 : 1);
+        std::unique_lock<std::mutex> lk(crs->mu);
+        for (;;) {
+            if (!crs->extending && crs->waiting_ext == 0) {
+                int pick = -1;
+                for (int k = 0; k < max_slots && pick < 0; ++k) if (!crs->busy[k] && crs->slot[k].ready) pick = k;
+                for (int k = 0; k < max_slots && pick < 0; ++k) if (!crs->busy[k]) pick = k;              // not created yet
+                if (pick >= 0) {
+                    crs->busy[pick] = true; ++crs->leases;
+                    if (crs->slot[pick].ready) { i = pick; return; }
+                    lk.unlock();
+                    const int rc = slot_create(crs, crs->slot[pick]);                                     // device allocations: outside the lock
+                    lk.lock();
+                    if (rc == ZKG_OK) { i = pick; return; }
+                    slot_destroy(crs->slot[pick]);
+                    crs->busy[pick] = false; --crs->leases; crs->cv.notify_all();
+                    if (pick == 0) return;                                                                // not even one slot: give up (i stays -1)
+                    // no memory for another slot: wait for one of the existing ones
+                    crs->cv.wait(lk, [&] { for (int k = 0; k < max_slots; ++k) if (!crs->busy[k] && crs->slot[k].ready) return true; return false; });
+                    continue;
+                }
+            }
+            crs->cv.wait(lk);
+        }
+    }
+    ~SlotLease() {
+        if (i < 0) return;
+        std::lock_guard<std::mutex> lk(crs->mu);
+        crs->busy[i] = false; --crs->leases; crs->cv.notify_all();
+    }
+    bool ok() const { return i >= 0; }
+    ProverSlot &S() { return crs->slot[i]; }
+};
+
 static int zkg_qap_witness_h_impl(const zkg_crs *crs_, const uint64_t *witness, uint64_t *h_out) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !h_out || (crs->n && !witness)) { set_error("zkg_qap_witness_h: bad argument"); return ZKG_ERROR; }
-    std::lock_guard<std::mutex> lk(crs->mu);
-    ProverSlot &S = crs->slot[0];
+    SlotLease lease(crs);
+    if (!lease.ok()) return ZKG_ERROR;
+    ProverSlot &S = lease.S();
     WitnessSrc W; W.dense = witness;
     if (compute_h_matvec(crs, S, W, false) || compute_h_transforms(crs, S)) return ZKG_ERROR;
     ZK_HIP(hipStreamSynchronize(S.stream));
@@ -638,7 +687,20 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         const size_t listed = S.flag_host[1];
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
         const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
-        if (listed && (S.flag_host[2] || !crs->sub.count) && subset_extend(crs, S, listed)) return ZKG_ERROR;
+        if (listed && (S.flag_host[2] || !crs->sub.count)) {
+            // the tables are shared by the key's slots: extend them only while no other proof is using them (see zkg_crs)
+            std::unique_lock<std::mutex> lk(crs->mu);
+            ++crs->waiting_ext; crs->cv.notify_all();
+            crs->cv.wait(lk, [&] { return !crs->extending && crs->leases - crs->waiting_ext == 0; });
+            --crs->waiting_ext; crs->extending = true;
+            lk.unlock();
+            const int rc_ext = subset_extend(crs, S, listed);
+            lk.lock();
+            crs->extending = false; crs->cv.notify_all();
+            lk.unlock();
+            if (rc_ext) return ZKG_ERROR;
+        }
+        msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w);   // (another slot's proof may have built the tables)
         const uint32_t *pos = crs->sub.pos.as<uint32_t>();
         // bucket method: the subset tables, addressed through the element positions; flat sums over the ones: the queries as uploaded
         const MsmBases g1[3] = {table_set(crs->sub.A, false, 0, pos), table_set(crs->sub.B1, false, 0, pos), table_set(crs->sub.L, false, 0, pos)}, b2 = table_set(crs->sub.B2, true, 0, pos);
@@ -749,8 +811,9 @@ static int groth16_prove_impl(const zkg_crs *crs_, const uint64_t *witness, cons
                               uint8_t *proof_out, size_t *proof_len) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !witness)) { set_error("zkg_groth16_prove: bad argument"); return ZKG_ERROR; }
-    std::lock_guard<std::mutex> lk(crs->mu);
-    ProverSlot &S = crs->slot[0];
+    SlotLease lease(crs);
+    if (!lease.ok()) return ZKG_ERROR;
+    ProverSlot &S = lease.S();
     WitnessSrc W; W.dense = witness;
     if (prove_enqueue(crs, S, W, r_, s_, check_satisfied != 0)) { slot_drain(crs, S); return ZKG_ERROR; }
     return prove_finish(crs, S, proof_out, proof_len);
@@ -765,8 +828,9 @@ static int groth16_prove_sparse_impl(const zkg_crs *crs_, const uint8_t *tags, c
     if (!crs || !r_ || !s_ || !proof_out || !proof_len || (crs->n && !tags) || (count && (!full_index || !full_values)) || count > crs->n) {
         set_error("zkg_groth16_prove_sparse: bad argument"); return ZKG_ERROR;
     }
-    std::lock_guard<std::mutex> lk(crs->mu);
-    ProverSlot &S = crs->slot[0];
+    SlotLease lease(crs);
+    if (!lease.ok()) return ZKG_ERROR;
+    ProverSlot &S = lease.S();
     WitnessSrc W; W.tags = tags; W.idx = full_index; W.vals = full_values; W.count = count;
     if (prove_enqueue(crs, S, W, r_, s_, check_satisfied != 0)) { slot_drain(crs, S); return ZKG_ERROR; }
     return prove_finish(crs, S, proof_out, proof_len);
