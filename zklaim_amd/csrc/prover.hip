@@ -694,7 +694,8 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
             crs->cv.wait(lk, [&] { return !crs->extending && crs->leases - crs->waiting_ext == 0; });
             --crs->waiting_ext; crs->extending = true;
             lk.unlock();
-            const int rc_ext = subset_extend(crs, S, listed);
+            int rc_ext = ZKG_ERROR;
+            try { rc_ext = subset_extend(crs, S, listed); } catch (...) { set_error("prover: witness table extension failed"); }   // the flag below must be cleared whatever happens
             lk.lock();
             crs->extending = false; crs->cv.notify_all();
             lk.unlock();
