@@ -8,8 +8,8 @@
 //
 // What differs from the reference by design: the pk is parsed and uploaded ONCE (zkg_crs_upload) instead
 // of on every call (libsnark_wrapper.cpp:230 + the by-value copy at snark.cpp:107-109); iFFT's 1/m and
-// the following cosetFFT's g^i are one fused table multiplication; the five queries live on the device as per-window tables
-// (2^(c w) P_i), so a multi-exponentiation is one bucket set, one reduction and no host doublings; the witness queries are split
+// the following cosetFFT's g^i are one fused table multiplication; the H query and the witness queries' non-bit elements live on
+// the device as per-window tables (2^(c w) P_i), so a multi-exponentiation is one bucket set, one reduction and no host doublings; the witness queries are split
 // as multi_exp_with_mixed_addition splits them (zeros skipped, ones summed flat, the rest through the bucket method, A / B_g1 / L
 // sharing one digit sort); the prover randomness (r, s) is an explicit input.
 #include "common.hpp"
@@ -679,7 +679,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     if (compute_h_matvec(crs, S, witness, check)) return ZKG_ERROR;
     lap(S, "upload + mat-vec enqueued");
     const size_t n = crs->n, l = crs->l, m = crs->m;
-    // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — ~3 % of a credential's
+    // The witness queries (libff multi_exp_with_mixed_addition): zeros skipped, ones summed flat, the rest — 0.1 % of a credential's
     // witness — through the bucket method as a gathered subset.  The count of "the rest" sizes the launches, so a helper thread waits
     // for the split (event 0), reads it and queues the four witness streams' work while this thread queues the critical path.
     auto witness_fn = [&]() -> int {
