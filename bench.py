@@ -41,7 +41,8 @@ def kernel_source_sha16():
 
 def stats_ms(samples):
     a = np.sort(np.asarray(samples, dtype=np.float64)) * 1e3
-    return {"median": round(float(np.median(a)), 4), "min": round(float(a[0]), 4), "max": round(float(a[-1]), 4), "n": int(a.size)}
+    return {"median": round(float(np.median(a)), 4), "min": round(float(a[0]), 4), "p95": round(float(np.percentile(a, 95)), 4),
+            "p99": round(float(np.percentile(a, 99)), 4), "max": round(float(a[-1]), 4), "n": int(a.size)}
 
 
 def splitmix_fr(n, seed):
@@ -71,18 +72,49 @@ G2_GEN_MONT = np.array([0x8e83b5d102bc2026, 0xdceb1935497b0172, 0xfbb8264797811a
                         0x64095b56c71856ee, 0xdc57f922327d3cbb, 0x55f935be33351076, 0x0da4a0e693fd6482], dtype=np.uint64)
 
 
-def msm_leg(zkg, torch, dist, logn, seed_off, steps, use_dist, world):
+def agree_ok(torch, dist, ok, use_dist):
+    """True only when EVERY rank reports ok: a rank that failed before a collective must not leave the others waiting in it"""
+    if not use_dist:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def all_ranks_same(torch, dist, point, use_dist):
+    """every rank holds the same combined point (12 limbs): compared across ranks, not assumed"""
+    if not use_dist:
+        return True
+    mine = torch.from_numpy(np.ascontiguousarray(point, dtype=np.uint64).view(np.int64).reshape(-1)).cuda()
+    every = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.int64, device="cuda")
+    dist.all_gather_into_tensor(every, mine)
+    return bool((every.view(dist.get_world_size(), -1) == mine).all().item())
+
+
+def msm_leg(zkg, torch, dist, logn, seed_off, steps, use_dist, world, check_cpu=False):
     """one more resident-input G1 MSM leg at 2^logn points per rank (BASELINE configs[4]: 2^23 per GPU = 2^26 over 8): per-step wall time,
-    max over ranks, barrier + synchronize on both sides like the headline loop"""
+    max over ranks, barrier + synchronize on both sides like the headline loop.  Self-checking: the rank's partial is compared with the sum
+    of its 2^20-point pieces (each through the two-pass sort the headline uses — a different code path from the one-pass sort of a 2^23-point
+    launch), with the oracle on all points when check_cpu, and the combined point is compared across ranks."""
     from zklaim_amd import dist as zdist
     n = 1 << logn
-    ks = splitmix_fr(n, SEED + 0x600 + seed_off); sc = splitmix_fr(n, SEED + 0x700 + seed_off)
-    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
-    d_bases = torch.empty((n, 8), dtype=torch.int64, device="cuda")
-    zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), n, d_bases.data_ptr())
-    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
-    del d_k
-    stream = torch.cuda.current_stream().cuda_stream
+    d_bases = d_sc = None; ok = True
+    try:                                                                  # everything before the first collective: a failure here is agreed on below
+        ks = splitmix_fr(n, SEED + 0x600 + seed_off); sc = splitmix_fr(n, SEED + 0x700 + seed_off)
+        d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+        d_bases = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+        zkg.fixed_base_g1_dev(G1_GEN_MONT, d_k.data_ptr(), n, d_bases.data_ptr())
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        del d_k
+        stream = torch.cuda.current_stream().cuda_stream
+        part0 = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)
+        piece = min(n, 1 << 20)
+        pieces = np.stack([zkg.msm_g1_dev(d_bases[lo:].data_ptr(), d_sc[lo:].data_ptr(), piece, stream=stream) for lo in range(0, n, piece)])
+        pieces_ok = bool(np.array_equal(zkg.g1_sum(pieces), part0))
+    except Exception as exc:
+        print(f"msm leg 2^{logn}: setup failed on this rank:", exc, file=sys.stderr); ok = False
+    if not agree_ok(torch, dist, ok, use_dist):
+        return None
 
     def step():
         part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)
@@ -92,7 +124,7 @@ def msm_leg(zkg, torch, dist, logn, seed_off, steps, use_dist, world):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-    step(); step()
+    step(); result = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -104,8 +136,18 @@ def msm_leg(zkg, torch, dist, logn, seed_off, steps, use_dist, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     per = dt / steps
-    return {"points_per_gpu": n, "total_points": n * world, "n_gpus": world, "steps": steps, "ms_per_step": round(per * 1e3, 3),
-            "GBps_algorithmic": round(BYTES_PER_POINT * n * world / per / 1e9, 3)}
+    out = {"points_per_gpu": n, "total_points": n * world, "n_gpus": world, "steps": steps, "ms_per_step": round(per * 1e3, 3),
+           "GBps_algorithmic": round(BYTES_PER_POINT * n * world / per / 1e9, 3), "partial_equals_sum_of_2p20_pieces": pieces_ok,
+           "all_ranks_same_result": all_ranks_same(torch, dist, result, use_dist)}
+    if check_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import zkoracle
+        threads = zkoracle.num_threads()
+        t1 = time.perf_counter()
+        ref = zkoracle.msm_g1(d_bases.cpu().numpy().view(np.uint64), sc, zkoracle.BDLO12, threads)
+        out["cpu_check"] = {"gpu_matches_cpu": bool(np.array_equal(ref, part0)), "seconds": round(time.perf_counter() - t1, 2), "cores": threads, "kind": "port",
+                            "sample": f"all 2^{logn} points of this leg, oracle BDLO12 bucket method, chunked over {threads} threads"}
+    return out
 
 
 def extras(zkg, torch, args, with_cpu):
@@ -147,7 +189,7 @@ def extras(zkg, torch, args, with_cpu):
                                           "gpu_matches_cpu": bool(np.array_equal(d_a.cpu().numpy().view(np.uint64), ref))}
 
     # BASELINE configs[4]'s per-GPU share (2^23 of the 2^26 points), and on request the whole 2^26 job on this one GPU (the strong-scaling reference)
-    out["msm_config5_share_2p23"] = msm_leg(zkg, torch, None, 23, 0, 5, False, 1)
+    out["msm_config5_share_2p23"] = msm_leg(zkg, torch, None, 23, 0, 5, False, 1, check_cpu=with_cpu)
     if args.config5_reference:
         out["msm_config5_single_gpu_2p26"] = msm_leg(zkg, torch, None, 26, 0, 3, False, 1)
     out["groth16_prove"] = prove_leg(zkg, torch, args, with_cpu, args.prove_logm)
@@ -195,12 +237,20 @@ def prove_leg(zkg, torch, args, with_cpu, logm):
         crs.prove_sparse(tags, fidx, fvals, rs[0], rs[1])
         each_sparse.append(time.perf_counter() - t0)
     dt_sparse = sum(each_sparse) / reps
+    # latency tail: many proofs back to back on the resident key (the seam's sparse form), median / p95 / p99 / max
+    tail_n = 1000 if m <= (1 << 18) else 300
+    tail = []
+    for _ in range(tail_n):
+        t0 = time.perf_counter()
+        crs.prove_sparse(tags, fidx, fvals, rs[0], rs[1])
+        tail.append(time.perf_counter() - t0)
     A, B, C = ck.csr()
     nnz = int(len(A[1]) + len(B[1]) + len(C[1]))
     alg_bytes = 7 * 64 * m + 96 * (nv + 1) + (128 + 64 + 32) * (nv + 1) + 96 * (m - 1) + 96 * (nv - l)
     g = {"circuit": f"zklaim_gadget, {k_payloads} payloads (SHA-256 + 5 comparisons each)", "log_m": logm, "domain_size": int(m), "num_variables": int(nv), "num_inputs": int(l),
          "num_constraints": int(ncons), "nnz": nnz, "ms_per_proof": round(dt * 1e3, 3), "proofs_per_sec": round(1.0 / dt, 3),
          "ms_per_proof_stats": stats_ms(each), "ms_per_proof_sparse_witness": round(dt_sparse * 1e3, 3), "ms_per_proof_sparse_witness_stats": stats_ms(each_sparse),
+         "latency_tail_sparse_witness": stats_ms(tail),
          "timing_note": "wall clock around the C-ABI call: witness H2D (dense: 32 B per variable; sparse: tags + listed values), all device work, proof D2H, host assembly", "sparse_witness_same_bytes": bool(rc_s == 0 and proof_s == proof),
          "algorithmic_bytes_per_proof": int(alg_bytes), "GBps_algorithmic": round(alg_bytes / dt / 1e9, 2), "stage_ms": [round(x, 3) for x in crs.stage_ms()],
          "stage_names": ["r1cs_matvec", "7_ntt+pointwise", "witness_A_Bg1_L_bucket_method", "-", "witness_Bg2_bucket_method", "msm_H", "-", "wall_total_incl_host_assembly"],
@@ -315,6 +365,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches = zkg.timing_dominant_ms()
+    same_everywhere = all_ranks_same(torch, dist, result, use_dist)          # outside the timed region
     # SURVEY.md section 8(d)'s other form of the same step: the scalars start in (pinned) HOST memory and their 32 B x n upload is inside the timed
     # call, bases resident.  Reported next to `value`, never as `value`.
     h2d = None
@@ -340,7 +391,7 @@ def main():
     line = {
         "metric": "Groth16 proofs/sec (zklaim gadget, alt_bn128) + G1 MSM GB/s vs HBM roofline", "metric_component": "G1 MSM GB/s (value, unit); Groth16 proofs/sec of the zklaim gadget in extras.groth16_prove and proofs_per_sec", "value": round(value, 3), "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_stats": stats_ms(per_step),
-        "incl_scalar_h2d": h2d, "higher_is_better": True,
+        "incl_scalar_h2d": h2d, "all_ranks_same_result": same_everywhere, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32x8-montgomery (254-bit Fq/Fr)", "data": "synthetic",
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
@@ -419,10 +470,8 @@ def main():
             line["proofs_per_sec_note"] = f"{world} independent prover replicas (one per GPU), zklaim gadget, 8 payloads, m = 2^18"
     if (world > 1 or (use_dist and os.environ.get("ZKG_BENCH_TEST_REPLICAS"))) and not args.no_extras:      # (the env switch lets one GPU rehearse this branch)
         # BASELINE configs[4]: 2^23 points per GPU (2^26 at 8 GPUs), same exchange; every rank takes part, rank 0 reports
-        try:
-            c5 = msm_leg(zkg, torch, dist, 23, 0x100 * rank, 3, use_dist, world)
-        except Exception as exc:
-            print("config-5 leg failed:", exc, file=sys.stderr); c5 = None
+        # (msm_leg agrees on every rank's setup before its first collective and returns None on all ranks if one of them failed)
+        c5 = msm_leg(zkg, torch, dist, 23, 0x100 * rank, 3, use_dist, world)
         if rank == 0 and c5:
             line["msm_config5"] = c5
     if rank == 0:

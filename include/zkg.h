@@ -152,7 +152,8 @@ int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]);
  *      zkg_msm_g1_multi: scalars n x 4 canonical limbs (HOST pointer).  One host thread per shard uploads that shard's scalar
  *      slice and runs the complete single-GPU Pippenger; the ndev partial points are added on the host (RCCL has no elliptic-curve
  *      reduction; the exchange is 96 bytes per GPU).  partials_jac (optional, ndev x 12 limbs) receives the per-shard results.
- *      Result == zkg_msm_g1 on the same inputs, bit for bit.                                                                  */
+ *      Result == zkg_msm_g1 on the same inputs, bit for bit.  Calls on one handle take turns (a mutex inside the handle: a call owns
+ *      every shard's scalar buffer, workspace and stream); different handles run side by side.                                */
 typedef struct zkg_msm_shards zkg_msm_shards;
 int zkg_init_multi(const int *devices, int ndev);
 zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const int *devices, int ndev);

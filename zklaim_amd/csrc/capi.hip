@@ -366,6 +366,7 @@ namespace { struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto
 struct zkg_msm_shards {
     struct Shard { int device = 0; size_t first = 0, n = 0; DevBuf bases, scalars; MsmJob *job = nullptr; };
     std::vector<Shard> shards; size_t n = 0;
+    std::mutex mu;                       // a call owns every shard's scalar buffer, job workspace and stream: callers of one handle take turns
 };
 
 int zkg_init_multi(const int *devices, int ndev) {
@@ -425,6 +426,7 @@ size_t zkg_msm_g1_shards_count(const zkg_msm_shards *h, size_t *points) { if (po
 static int zkg_msm_g1_multi_impl(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
     zkg_msm_shards *h = const_cast<zkg_msm_shards *>(h_);
     if (!h || !out_jac || (h->n && !scalars)) { set_error("zkg_msm_g1_multi: bad argument"); return ZKG_ERROR; }
+    std::lock_guard<std::mutex> calls_take_turns(h->mu);
     const size_t ns = h->shards.size();
     std::vector<G1> part(ns, G1::inf()); std::vector<int> rc(ns, ZKG_OK);
     auto run = [&](size_t i) {

@@ -206,10 +206,10 @@ static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     std::thread parser(parse_constraint_system, rd, ncons, nA, std::ref(cs));
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_guard{parser};       // on every return path, also an exception's
     // ---- ... while the GPU decompresses the points (one lane per point) straight into the buffers the resident key is built from
-    DevBuf d_rec, d_flag, d_small, dA, dB1, dB2, dBv1, dBv2, dH, dL, d_idx;
+    // (scoped: hundreds of MB of staging are handed back on every way out of this function, an exception's unwinding included)
+    ScopedDevBuf d_rec, d_flag, d_small, dA, dB1, dB2, dBv1, dBv2, dH, dL, d_idx;
     auto fail = [&](const char *msg) -> zkg_crs * {
         if (msg) set_error(msg);
-        for (DevBuf *b : {&d_rec, &d_flag, &d_small, &dA, &dB1, &dB2, &dBv1, &dBv2, &dH, &dL, &d_idx}) b->release();
         return nullptr;
     };
     if (d_flag.reserve(4) || d_small.reserve(3 * 64 + 2 * 128) || dA.reserve(nA * 64) || dB1.reserve(domain * 64) || dB2.reserve(domain * 128) || dBv1.reserve(nval * 64 + 16) ||
@@ -254,8 +254,7 @@ static zkg_crs *crs_upload_blob_impl(const void *blob, size_t len) {
     };
     zkg_crs *crs = crs_upload_device_queries(&pk, system_ready);
     lap("resident key built");
-    (void)fail(nullptr);                                                        // releases the staging buffers (no message)
-    return crs;
+    return crs;                                                                 // (the staging buffers are released by their scope)
 }
 
 // Host-only walk of a pk blob, the loader's parsing without the GPU: sections, index list, every constraint's terms.  out (optional):

@@ -25,6 +25,15 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// a DevBuf that lives for one scope (staging of a key load, of a table build): released on every way out, an exception's included.
+// DevBuf itself has no destructor on purpose — resident buffers are members of objects with explicit lifetimes and are copied into caches.
+struct ScopedDevBuf : DevBuf {
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf &) = delete;
+    ScopedDevBuf &operator=(const ScopedDevBuf &) = delete;
+    ~ScopedDevBuf() { release(); }
+};
+
 // HIP-event timing of the dominant kernel (bench.py's roofline.achieved), on the launch stream
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs; size_t used = 0; bool enabled = true, pending = false;

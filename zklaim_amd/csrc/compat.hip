@@ -16,7 +16,9 @@
 #include <cstring>
 #include <algorithm>
 #include <future>
+#include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <random>
 
@@ -37,17 +39,28 @@ void circuit_release_csr(zkg_circuit *c, zk::OwnedCsr &out);                    
 
 namespace {
 
+// g_mu guards g_inited and the key cache's MAP only — never a key load, a witness pass or a proof.  Callers of one resident key meet again
+// at that key's prover slots (prover.hip SlotLease: up to three proofs in flight below m = 2^18), callers of different keys nowhere.
 std::mutex g_mu;
+std::condition_variable g_cv;                                // a key that was being loaded has finished loading (or failed)
 bool g_inited = false;
 struct Digest128 { uint64_t a = 0, b = 0; bool operator==(const Digest128 &o) const { return a == o.a && b == o.b; } };
-struct CachedCrs { size_t size; Digest128 full; zkg_crs *crs; };
-std::map<uint64_t, CachedCrs> g_crs_cache;                    // one upload per key, not per proof (the reference re-parses ctx->pk on every call)
+// One resident key.  `loading`: the thread that inserted the entry is still parsing / uploading the blob; later callers of the same key wait
+// for it instead of uploading a second copy.  The key itself is shared: an entry evicted from the map (at most four stay) lives on until
+// the last proof using it has returned.
+struct CachedCrs { size_t size = 0; Digest128 full; std::shared_ptr<zkg_crs> crs; bool loading = true, failed = false; };
+std::map<uint64_t, std::shared_ptr<CachedCrs>> g_crs_cache;    // one upload per key, not per proof (the reference re-parses ctx->pk on every call)
+std::shared_ptr<zkg_crs> share_crs(zkg_crs *c) { return std::shared_ptr<zkg_crs>(c, [](zkg_crs *p) { zkg_crs_free(p); }); }
 
-int ensure_init() {
-    if (g_inited) return 0;
-    const char *dev = getenv("ZKG_DEVICE");
-    if (zkg_init(dev ? atoi(dev) : 0)) return 1;
-    g_inited = true;
+int seam_device() { static const int d = [] { const char *dev = getenv("ZKG_DEVICE"); return dev ? atoi(dev) : 0; }(); return d; }
+int ensure_init() {                                          // caller holds g_mu
+    if (!g_inited) {
+        if (zkg_init(seam_device())) return 1;
+        g_inited = true;
+    }
+    // the current device is per thread: every thread that enters the seam is bound to the seam's device once
+    static thread_local bool bound = false;
+    if (!bound) { if (hipSetDevice(seam_device()) != hipSuccess) return 1; bound = true; }
     return 0;
 }
 // Two digests of a pk blob.  `sampled` is the cache's lookup key: head, tail and 128 strided windows (80 KB), microseconds on a
@@ -104,8 +117,7 @@ extern "C" {
 
 static int libsnark_trusted_setup_impl(zklaim_ctx *ctx) {
     if (!ctx) return ZKLAIM_ERROR;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (ensure_init()) return ZKLAIM_ERROR;
+    { std::lock_guard<std::mutex> lk(g_mu); if (ensure_init()) return ZKLAIM_ERROR; }
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
     auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg seam setup] %-24s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
@@ -145,33 +157,69 @@ int libsnark_trusted_setup(zklaim_ctx *ctx) {
 }
 
 
-static int libsnark_prove_impl(zklaim_ctx *ctx) {
-    if (!ctx || !ctx->pk || !ctx->pk_size) return ZKLAIM_ERROR;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (ensure_init()) return ZKLAIM_ERROR;
-    const uint64_t key = sampled_digest(ctx->pk, ctx->pk_size);
-    auto adopt = [&](zkg_crs *c, const Digest128 &full) -> zkg_crs * {          // a freshly loaded key into the cache (at most four resident)
-        auto old = g_crs_cache.find(key);
-        if (old != g_crs_cache.end()) { zkg_crs_free(old->second.crs); g_crs_cache.erase(old); }
-        if (g_crs_cache.size() >= 4) { for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs); g_crs_cache.clear(); }
-        g_crs_cache[key] = {ctx->pk_size, full, c};
-        return c;
-    };
-    auto upload = [&](const Digest128 &full) -> zkg_crs * {
-        zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
-        return c ? adopt(c, full) : nullptr;
-    };
-    zkg_crs *crs = nullptr;
-    bool speculative = false;                                    // a cache hit by the sampled digest: confirmed by the full one below
-    auto it = g_crs_cache.find(key);
-    if (it != g_crs_cache.end() && it->second.size == ctx->pk_size) { crs = it->second.crs; speculative = true; }
-    else {                                                       // a new key: its full digest (every byte) is computed while the key loads
+// The resident key of ctx->pk: found in the cache (a hit by the sampled digest is `speculative` until the full digest confirms it), or
+// loaded by THIS caller — with the map's lock released — while later callers of the same key wait for that load instead of repeating it.
+static std::shared_ptr<zkg_crs> resident_key(const zklaim_ctx *ctx, uint64_t key, bool &speculative, Digest128 &recorded_full) {
+    std::shared_ptr<CachedCrs> entry;
+    {
+        std::unique_lock<std::mutex> lk(g_mu);
+        if (ensure_init()) return nullptr;
+        for (;;) {
+            auto it = g_crs_cache.find(key);
+            if (it == g_crs_cache.end() || it->second->size != ctx->pk_size) break;
+            std::shared_ptr<CachedCrs> e = it->second;
+            g_cv.wait(lk, [&] { return !e->loading; });
+            if (!e->failed) { speculative = true; recorded_full = e->full; return e->crs; }
+            // the load failed (its loader has erased the entry, or another caller has replaced it): look again
+        }
+        if (g_crs_cache.size() >= 4) g_crs_cache.clear();                 // at most four resident keys; keys in use live on through their shared owners
+        entry = std::make_shared<CachedCrs>();
+        entry->size = ctx->pk_size;
+        g_crs_cache[key] = entry;                                          // (replaces an entry of another size under the same sampled digest)
+    }
+    // a new key: its full digest (every byte) is computed while the key loads
+    std::shared_ptr<zkg_crs> crs;
+    Digest128 full;
+    try {
         std::future<Digest128> digest = std::async(std::launch::async, [&] { return full_digest(ctx->pk, ctx->pk_size); });
         zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
-        const Digest128 full = digest.get();
-        if (!c) return ZKLAIM_ERROR;
-        crs = adopt(c, full);
+        full = digest.get();
+        if (c) crs = share_crs(c);
+    } catch (...) { crs.reset(); }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        entry->loading = false;
+        if (crs) { entry->crs = crs; entry->full = full; }
+        else {
+            entry->failed = true;
+            auto it = g_crs_cache.find(key);
+            if (it != g_crs_cache.end() && it->second == entry) g_crs_cache.erase(it);
+        }
     }
+    g_cv.notify_all();
+    speculative = false;
+    return crs;
+}
+// a speculative hit turned out to be another key (same size and samples, different bytes): load this one and put it in the other's place
+static std::shared_ptr<zkg_crs> replace_key(const zklaim_ctx *ctx, uint64_t key, const Digest128 &full) {
+    zkg_crs *c = zkg_crs_upload_blob(ctx->pk, ctx->pk_size);
+    if (!c) return nullptr;
+    std::shared_ptr<zkg_crs> crs = share_crs(c);
+    auto entry = std::make_shared<CachedCrs>();
+    entry->size = ctx->pk_size; entry->full = full; entry->crs = crs; entry->loading = false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_crs_cache.find(key);
+    if (it == g_crs_cache.end() || !it->second->loading) g_crs_cache[key] = entry;      // (an entry someone is loading right now is theirs to finish)
+    return crs;
+}
+
+static int libsnark_prove_impl(zklaim_ctx *ctx) {
+    if (!ctx || !ctx->pk || !ctx->pk_size) return ZKLAIM_ERROR;
+    const uint64_t key = sampled_digest(ctx->pk, ctx->pk_size);
+    bool speculative = false;                                    // a cache hit by the sampled digest: confirmed by the full one below
+    Digest128 recorded_full;
+    std::shared_ptr<zkg_crs> crs = resident_key(ctx, key, speculative, recorded_full);
+    if (!crs) return ZKLAIM_ERROR;
     // the witness only: the constraint system already sits on the GPU inside the resident key, and pb.is_satisfied()
     // (snark.cpp:121-124) is evaluated there, fused with the R1CS mat-vec of the prover (check_satisfied = 1)
     zkg_circuit *ck = zkg_zklaim_witness_new(ctx);
@@ -187,14 +235,14 @@ static int libsnark_prove_impl(zklaim_ctx *ctx) {
         std::future<Digest128> confirm;
         if (speculative) confirm = std::async(std::launch::async, [&] { return full_digest(ctx->pk, ctx->pk_size); });     // under the GPU's work
         // a key made for another payload count has another variable count: refuse instead of reading past the witness
-        if (zkg_circuit_num_variables(ck) != zkg_crs_num_variables(crs)) set_error("libsnark_prove: ctx->pk was generated for a different circuit (variable count differs)");
-        else prc = zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s, 1, proof, &len);
+        if (zkg_circuit_num_variables(ck) != zkg_crs_num_variables(crs.get())) set_error("libsnark_prove: ctx->pk was generated for a different circuit (variable count differs)");
+        else prc = zkg_groth16_prove_sparse(crs.get(), tags, fidx, fval, nfull, r, s, 1, proof, &len);
         if (speculative) {
             const Digest128 full = confirm.get();
-            if (!(full == g_crs_cache[key].full)) {              // same size and samples, different bytes: not the resident key after all
+            if (!(full == recorded_full)) {                      // same size and samples, different bytes: not the resident key after all
                 prc = ZKG_ERROR;
-                crs = upload(full);
-                if (crs && zkg_circuit_num_variables(ck) == zkg_crs_num_variables(crs)) prc = zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s, 1, proof, &len);
+                crs = replace_key(ctx, key, full);
+                if (crs && zkg_circuit_num_variables(ck) == zkg_crs_num_variables(crs.get())) prc = zkg_groth16_prove_sparse(crs.get(), tags, fidx, fval, nfull, r, s, 1, proof, &len);
             }
         }
     }
@@ -227,8 +275,7 @@ int libsnark_verify(zklaim_ctx *ctx) {
 // drops the resident keys cached by libsnark_prove (tests / long-running hosts)
 void zkg_compat_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto &kv : g_crs_cache) zkg_crs_free(kv.second.crs);
-    g_crs_cache.clear();
+    g_crs_cache.clear();                                         // (a key still proving lives on until that proof returns)
 }
 
 }  // extern "C"

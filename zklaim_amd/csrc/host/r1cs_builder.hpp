@@ -63,11 +63,17 @@ struct Builder {
         }
         val.push_back(Fr::zero()); nz.push_back(0); return (Var)(val.size() - 1);
     }
-    // n consecutive fresh variables, first index returned (values zero).  A view that cannot supply them falls back to alloc()'s overrun path.
+    // n consecutive fresh variables, first index returned (values zero).  Callers write all n of them as a block (the word-level gadgets
+    // store 32 / 64 tags at once), so a view that cannot supply them must still hand back n indices it owns: the LAST n of its own range
+    // (stale stand-ins, like alloc()'s), with the overrun recorded for the caller to report.  A view narrower than n has no such block:
+    // it returns the largest in-range start and the caller's check of `overrun` refuses the circuit (views are sized in whole payloads,
+    // thousands of variables; the widest block is ~100).
     Var alloc_block(uint32_t n) {
         if (root) {
             if (cursor + n <= cursor_end) { Var f = cursor; cursor += n; return f; }
-            Var f = alloc(); for (uint32_t i = 1; i < n; ++i) (void)alloc(); return f;
+            overrun = true; cursor = cursor_end;
+            if (cursor_end - cursor_begin >= n) return cursor_end - n;
+            return root->val.size() > n ? (Var)(root->val.size() - n) : (Var)0;          // in bounds of the root's storage whatever happens
         }
         return (Var)extend(n);
     }

@@ -41,8 +41,10 @@ struct DevCsr { DevBuf rowptr, col, val; size_t nnz = 0; };
 struct Helper {
     std::thread th; std::mutex mu; std::condition_variable cv;
     std::function<int()> task; bool has_task = false, done = true, stop = false; int result = 0;
-    void start() { th = std::thread([this] { loop(); }); }
+    int device = 0;                       // the key's device: a new thread starts on device 0, and this one launches kernels on the slot's streams
+    void start() { (void)hipGetDevice(&device); th = std::thread([this] { loop(); }); }
     void loop() {
+        (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&] { return has_task || stop; });
@@ -577,6 +579,10 @@ static MsmBases query_set(const DevBuf &q, bool g2, uint32_t index_sub) { MsmBas
 static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     zkg_crs::SubsetTables &T = crs->sub;
     const size_t n1 = (size_t)crs->n + 1; hipStream_t s = S.stream_o;
+    // From here until one of the two success exits the key has NO witness tables: pos / idx / the tables / the window size are rewritten
+    // below in several steps, and a failure between them (a device allocation under memory pressure) must leave a state the next proof
+    // recognises — count == 0 sends it back here — instead of old tables under a new position map.
+    T.count = 0;
     std::vector<uint32_t> li(listed);
     ZK_HIP(hipMemcpyAsync(li.data(), S.wlisted.p, listed * 4, hipMemcpyDeviceToHost, s));
     ZK_HIP(hipStreamSynchronize(s));
@@ -595,9 +601,8 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     // bucket sets keep this latency-bound work light: the digit sort's LDS histogram is 2^(c-1) counters, the fold and the reduction
     // shrink with it.
     int lg_count = 0; while (((size_t)1 << (lg_count + 1)) <= count) ++lg_count;
-    crs->c_w = crs->c_w_forced ? crs->c_w_forced : std::min(14, std::max(10, lg_count + 2));
-    msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w);
-    DevBuf stage, stage2;
+    const int c_new = crs->c_w_forced ? crs->c_w_forced : std::min(14, std::max(10, lg_count + 2));     // becomes crs->c_w once the tables stand
+    ScopedDevBuf stage, stage2;                                                                       // released on every way out
     if (stage.reserve(3 * count * sizeof(G1Affine) + 16) || stage2.reserve(count * sizeof(G2Affine) + 16)) return ZKG_ERROR;
     const uint32_t *d_idx = T.idx.as<uint32_t>();
     static const size_t host_limit = getenv("ZKG_SUBSET_HOST_LIMIT") ? (size_t)atoi(getenv("ZKG_SUBSET_HOST_LIMIT")) : 1024;   // tuning aid
@@ -615,8 +620,8 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
                          hip_ok(hipMemcpyAsync(p2.data(), stage2.p, count * sizeof(G2Affine), hipMemcpyDeviceToHost, s), "D2H", __FILE__, __LINE__) &&
                          hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);
         stage.release(); stage2.release();
-        if (!got) { T.count = 0; return ZKG_ERROR; }
-        const int c = crs->c_w, W = (254 + c) / c;                               // = (SCALAR_BITS + c - 1) / c of window_table_build
+        if (!got) return ZKG_ERROR;
+        const int c = c_new, W = (254 + c) / c;                               // = (SCALAR_BITS + c - 1) / c of window_table_build
         std::vector<G1Affine> t1((size_t)3 * W * count); std::vector<G2Affine> t2((size_t)W * count);
         auto levels = [&](auto base, auto *out /* level w of this point at out[w * count] */) {
             typedef decltype(base.x) F;
@@ -650,23 +655,23 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
         up = up && T.B2.buf.reserve((size_t)W * count * sizeof(G2Affine)) == 0 &&
              hip_ok(hipMemcpyAsync(T.B2.buf.p, t2.data(), (size_t)W * count * sizeof(G2Affine), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__);
         up = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__) && up;          // (host vectors go out of scope)
-        if (!up) { T.count = 0; return ZKG_ERROR; }
-        T.count = count; ++T.rebuilds;
+        if (!up) return ZKG_ERROR;
+        crs->c_w = c_new; T.count = count; ++T.rebuilds;
         if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u, levels on the host)\n", count, n1, T.rebuilds);
         return ZKG_OK;
     }
     // the G2 table on the B_g2 job's stream (idle as well), beside the three G1 tables: a few thousand points per launch are latency chains
     hipStream_t s2 = msm_job_stream(S.job_w2);
     bool ok = hip_ok(hipEventRecord(S.ev[11], s), "event", __FILE__, __LINE__) && hip_ok(hipStreamWaitEvent(s2, S.ev[11], 0), "wait", __FILE__, __LINE__);   // idx is up
-    int rc = !ok || gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage2.as<G2Affine>(), s2) || window_table_build_g2(T.B2, stage2.as<G2Affine>(), count, crs->c_w, s2) ||
-             gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.A, stage.as<G1Affine>(), count, crs->c_w, s) ||
-             gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.B1, stage.as<G1Affine>(), count, crs->c_w, s) ||
-             gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), stage.as<G1Affine>(), s) || window_table_build_g1(T.L, stage.as<G1Affine>(), count, crs->c_w, s);
+    int rc = !ok || gather_points_g2(crs->B_g2.as<G2Affine>(), d_idx, count, 0, stage2.as<G2Affine>(), s2) || window_table_build_g2(T.B2, stage2.as<G2Affine>(), count, c_new, s2) ||
+             gather_points_g1(crs->A_query.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.A, stage.as<G1Affine>(), count, c_new, s) ||
+             gather_points_g1(crs->B_g1.as<G1Affine>(), d_idx, count, 0, stage.as<G1Affine>(), s) || window_table_build_g1(T.B1, stage.as<G1Affine>(), count, c_new, s) ||
+             gather_points_g1(crs->L_query.as<G1Affine>(), d_idx, count, (uint32_t)(crs->l + 1), stage.as<G1Affine>(), s) || window_table_build_g1(T.L, stage.as<G1Affine>(), count, c_new, s);
     const bool synced1 = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__), synced2 = hip_ok(hipStreamSynchronize(s2), "sync", __FILE__, __LINE__);
     const bool synced = synced1 && synced2;                                     // (both streams waited for: host vectors and staging go out of scope)
     stage.release(); stage2.release();
-    if (rc || !synced) { T.count = 0; return ZKG_ERROR; }
-    T.count = count; ++T.rebuilds;
+    if (rc || !synced) return ZKG_ERROR;
+    crs->c_w = c_new; T.count = count; ++T.rebuilds;
     if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u)\n", count, n1, T.rebuilds);
     return ZKG_OK;
 }
