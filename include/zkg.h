@@ -258,8 +258,15 @@ void zkg_compat_reset(void);
  *      here the generated v_mad_u64_u32 streams of csrc/mont_asm.inc).  Element-wise ON THE GPU, host pointers:
  *      field 0 = Fq, 1 = Fr (4 limbs per element), 2 = Fq2 (8 limbs);  op 0 mul, 1 add, 2 sub, 3 inverse, 4 to Montgomery form,
  *      5 from Montgomery form, 6 negate, 7 square (4 and 5: Fq / Fr only).  Inputs and outputs are Montgomery limbs except op 4's
- *      input and op 5's output (canonical); outputs are fully reduced.  b is read by ops 0-2 only.                                */
+ *      input and op 5's output (canonical); outputs are fully reduced.  b is read by ops 0-2 only.
+ *      Fq only, ops 10-14: the same arithmetic on the 9 x 29-bit representation of the bucket-accumulation kernel (csrc/fq29.hip.hpp),
+ *      entered and left through its conversions: 10 mul, 11 add, 12 sub, 13 a if a != b else 0 (its zero test), 14 the composite
+ *      (b-a)(a-b) - (b-a)^2 - 2ab with unnormalised intermediate sums, as the mixed addition chains them.                          */
 int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
+
+/* known-answer hook for the 29-bit group law of the bucket-reduction kernels (csrc/fq29.hip.hpp, xyzz29_add_quad): on the GPU,
+ * out[i] = a[i] + b[i], then `chain` rounds of x <- 2x + b[i]; points as normalised Jacobian (12 limbs), host pointers.          */
+int zkg_g1_add_quad29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac);
 
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
  * average device ms per launch of the dominant kernel over the calls since the last reset */

@@ -1,4 +1,4 @@
-"""CPU suite: the generated gfx950 instruction streams of the field arithmetic (zklaim_amd/csrc/mont_asm.inc).
+"""CPU suite: the generated gfx950 instruction streams of the field arithmetic (zklaim_amd/csrc/mont_asm.inc, f29_asm.inc).
 tools/gen_mont_asm.py interprets every stream it emits on Python integers: the Montgomery product against a*b*R^-1 mod p, the
 interleaved lazy add / sub against (a +- b) mod p with the [0, 2p) range invariant, for Fq and Fr, edge values included.  The
 committed .inc must be exactly what the generator produces (no hand edits)."""
@@ -20,6 +20,7 @@ def test_streams_simulate_correctly():
     g = _gen()
     g.selftest()
     g.selftest_addsub()
+    g.selftest_f29()                  # the 9 x 29-bit product / squaring of csrc/fq29.hip.hpp (f29_asm.inc): values and column bounds
 
 
 def test_hazard_distances():
@@ -47,6 +48,8 @@ def test_committed_inc_is_generated(tmp_path, monkeypatch):
     monkeypatch.setattr(g.os.path, "abspath", lambda p: str(fake_tools / "gen_mont_asm.py"))
     g.main()
     assert (tmp_path / "zklaim_amd" / "csrc" / "mont_asm.inc").read_text() == committed
+    committed29 = open(os.path.join(ROOT, "zklaim_amd", "csrc", "f29_asm.inc")).read()
+    assert (tmp_path / "zklaim_amd" / "csrc" / "f29_asm.inc").read_text() == committed29
 
 
 def test_random_products_against_python():

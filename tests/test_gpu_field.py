@@ -50,3 +50,50 @@ def test_field_ops_random_vs_oracle(zkg, oracle, field, p):
     assert ints(zkg.field_op(field, 2, am, bm), p) == [(x - y) % p for x, y in zip(pa, pb)]
     nz = [i for i, x in enumerate(pa) if x][:64]
     assert ints(zkg.field_op(field, 3, am[nz]), p) == [pow(pa[i], -1, p) for i in nz]
+
+
+def test_fq_29bit_representation_vs_integers(zkg):
+    """the 9 x 29-bit representation of the bucket-accumulation kernel (csrc/fq29.hip.hpp: Montgomery product without carry folds, limb-wise
+    add / sub with spread multiples of q, conversions to and from libff's 4 x 64-bit Montgomery form) against plain Python integers:
+    8192 random pairs plus the edges of the value range and pairs whose difference is 0 or a multiple of q away from it"""
+    p = Q
+    n = 8192
+    a = random_fr_canonical(n, 31); b = random_fr_canonical(n, 33)
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 253) % p, (1 << 255) % p, (1 << 232) - 1, 1 << 232, (1 << 29) - 1, 1 << 29, (p - 1) // 2]
+    ea = arr(edge); a[: len(edge)] = ea; b[len(edge): 2 * len(edge)] = ea; b[: len(edge)] = arr(list(reversed(edge)))
+    b[100:140] = a[100:140]                                                  # equal operands: differences that are zero
+    am = zkg.field_op(0, 4, a); bm = zkg.field_op(0, 4, b)
+    pa, pb = ints(a), ints(b)
+    assert ints(zkg.field_op(0, 10, am, bm), p) == [x * y % p for x, y in zip(pa, pb)]
+    assert ints(zkg.field_op(0, 11, am, bm), p) == [(x + y) % p for x, y in zip(pa, pb)]
+    assert ints(zkg.field_op(0, 12, am, bm), p) == [(x - y) % p for x, y in zip(pa, pb)]
+    assert ints(zkg.field_op(0, 13, am, bm), p) == [x if x != y else 0 for x, y in zip(pa, pb)]
+    assert ints(zkg.field_op(0, 14, am, bm), p) == [((y - x) * (x - y) - (y - x) ** 2 - 2 * x * y) % p for x, y in zip(pa, pb)]
+    # outputs are canonical limbs (below q), not merely congruent
+    out = zkg.field_op(0, 10, am, bm)
+    assert all(v < p for v in ints(out))
+
+
+def test_g1_quad_addition_29bit_vs_oracle(zkg, oracle):
+    """the 29-bit group law of the bucket-reduction kernels (csrc/fq29.hip.hpp xyzz29_add_quad, one DPP quad per addition) against the
+    oracle's Jacobian arithmetic: random pairs, P + P (the doubling branch), P + (-P), infinity on either side, and chains of sums of
+    sums (x <- 2x + b), which walk the value bounds the representation keeps between additions"""
+    n = 256
+    ks = random_fr_canonical(2 * n, 71)
+    pts = oracle.g1_fixed_base(oracle.g1_generator(), ks)                    # affine (x, y), 8 limbs each
+    one = arr([1], Q).reshape(4)
+    jac = np.concatenate([pts, np.tile(one, (2 * n, 1))], axis=1)            # normalised Jacobian: Z = 1
+    a, b = jac[:n].copy(), jac[n:].copy()
+    inf = np.concatenate([arr([0, 1, 0], Q).reshape(12)])
+    b[0] = a[0]                                                              # doubling
+    b[1] = a[1]; b[1, 4:8] = arr([Q - int(ints(a[1, 4:8], Q)[0])], Q).reshape(4)   # P + (-P)
+    a[2] = inf; b[3] = inf; a[4] = inf; b[4] = inf
+    for chain in (0, 1, 5):
+        got = zkg.g1_add_quad29(a, b, chain)
+        for i in range(n):
+            exp = oracle.g1_sum(np.stack([a[i], b[i]]))
+            for _ in range(chain):
+                exp = oracle.g1_sum(np.stack([exp, exp, b[i]]))
+            assert np.array_equal(got[i], exp), (chain, i)
+    lane = zkg.g1_add_quad29(a, b, -1)                                       # the one-lane form of the same addition
+    assert all(np.array_equal(lane[i], oracle.g1_sum(np.stack([a[i], b[i]]))) for i in range(n))

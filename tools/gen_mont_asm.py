@@ -135,6 +135,20 @@ def main():
     lines.append("#define ZK_MONT_MUL_CLOBBERS " + ", ".join(clob))
     open(dst, "w").write("\n".join(lines) + "\n")
     print("wrote", os.path.normpath(dst))
+    dst29 = os.path.join(here, "..", "zklaim_amd", "csrc", "f29_asm.inc")
+    l29 = ["// GENERATED by tools/gen_mont_asm.py (gen_f29) — do not edit.  9 x 29-bit Montgomery product / squaring, one 64-bit column, no carry folds.", ""]
+    for name, sq, dual in (("MUL", False, False), ("SQR", True, False), ("MUL2", False, True), ("SQR2", True, True)):
+        ins = gen_f29_dual(sq) if dual else gen_f29(sq)
+        l29.append(f"// {name}: {len(ins)} instructions, {sum(1 for t in ins if t.startswith('v_mad'))} v_mad_u64_u32")
+        l29.append(f"#define ZK_F29_{name}_ASM \\")
+        for t in ins:
+            l29.append(f'    "{t}\\n\\t" \\')
+        l29.append('    ""')
+        l29.append("")
+    l29.append("#define ZK_F29_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
+    l29.append("#define ZK_F29_CLOBBERS2 " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"v{i}"' for i in range(14, 25)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
+    open(dst29, "w").write("\n".join(l29) + "\n")
+    print("wrote", os.path.normpath(dst29))
 
 
 
@@ -227,6 +241,156 @@ def selftest_addsub():
             assert r < 2 * p and r % p == (a - b) % p, (name, "sub", a, b)
     print("selftest ok: interleaved add / sub streams keep [0, 2p) and agree with (a +- b) mod p for Fq and Fr")
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 9 x 29-bit Montgomery product (R' = 2^261) for csrc/fq29.hip.hpp: product scanning with ONE 64-bit column accumulator.  18 partial
+# products of 58 bits fit a column without overflowing, so there is no carry to fold — the v_addc_co_u32_e64 of the 32-bit stream costs
+# as much as a multiply-add on gfx950 (every VOP3-encoded instruction ~4.2 cycles, profiles/r3_mul_variants.txt).  Written as C++ the
+# compiler splits each column over two accumulators and joins them with a 64-bit add (17 v_lshl_add_u64 per product: 895 cycles); with
+# one inline-asm statement per multiply-add it pads every statement with s_nop.  One block for the whole product: 162 v_mad_u64_u32,
+# 9 v_mul_lo_u32, 17 v_lshrrev_b64, 17 v_and_b32 (VOP2, mask in an SGPR).
+# Fixed registers: column v[2:3], quotient digits v4..v12, q's limbs s16..s24, -1/q mod 2^29 in s25, the mask in s26.
+# Operands: %0-%8 result, %9-%17 a, %18-%26 b (for the squaring: b = 2 a, limb-wise; cross products i < j only, against the doubled limb).
+F29_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def gen_f29(square, col=2, m0=4, out0=0, a0=9, b0=18, consts=True):
+    """one product: column accumulator v[col:col+1], quotient digits v{m0}.., operands %{out0}.. result, %{a0}.. a, %{b0}.. b"""
+    q = F29_P
+    P = [(q >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
+    inv = (-pow(q, -1, 1 << 29)) % (1 << 29)
+    A = lambda i: f"%{a0 + i}"
+    B = lambda i: f"%{b0 + i}"
+    M = lambda i: f"v{m0 + i}"
+    SP = lambda j: f"s{16 + j}"
+    COL = f"v[{col}:{col + 1}]"
+    out = [f"s_mov_b32 s25, 0x{inv:08x}", "s_mov_b32 s26, 0x1fffffff", f"s_mov_b32 {SP(0)}, 0x{P[0]:08x}"] if consts else []
+    first = [True]
+
+    def mad(x, y):
+        out.append(f"v_mad_u64_u32 {COL}, vcc, {x}, {y}, " + ("0" if first[0] else COL))
+        first[0] = False
+
+    def ab_terms(k):
+        lo, hi = max(0, k - 8), min(k, 8)
+        if not square:
+            return [(A(i), B(k - i)) for i in range(lo, hi + 1)]
+        t = [(B(i), A(k - i)) for i in range(lo, hi + 1) if i < k - i]             # 2 a_i a_j once, i < j
+        if k % 2 == 0:
+            t.append((A(k // 2), A(k // 2)))
+        return t
+
+    for k in range(17):
+        for x, y in ab_terms(k):
+            mad(x, y)
+        if k < 9:
+            for i in range(k):
+                mad(M(i), SP(k - i))
+            out.append(f"v_mul_lo_u32 {M(k)}, v{col}, s25")
+            out.append(f"v_and_b32_e32 {M(k)}, s26, {M(k)}")
+            mad(M(k), SP(0))
+            if k < 8 and consts:
+                out.append(f"s_mov_b32 {SP(k + 1)}, 0x{P[k + 1]:08x}")
+        else:
+            for i in range(k - 8, 9):
+                mad(M(i), SP(k - i))
+            out.append(f"v_and_b32_e32 %{out0 + k - 9}, s26, v{col}")
+        out.append(f"v_lshrrev_b64 {COL}, 29, {COL}")
+    out.append(f"v_mov_b32_e32 %{out0 + 8}, v{col}")
+    if consts:
+        out.append("s_nop 1")     # a DPP move may read a result right behind the block: two wait states the compiler cannot see into the block for
+    return out
+
+
+def gen_f29_dual(square):
+    """two independent products, instruction by instruction: each chain's next multiply-add issues while the other's is in flight (a lone
+    column is a chain of dependent v_mad_u64_u32; at two wavefronts per SIMD its latency shows).  Operands: %0-%8 and %9-%17 the results,
+    %18-%26 a, %27-%35 b (first product), %36-%44 c, %45-%53 d (second product)."""
+    q = F29_P
+    P = [(q >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
+    inv = (-pow(q, -1, 1 << 29)) % (1 << 29)
+    head = [f"s_mov_b32 s25, 0x{inv:08x}", "s_mov_b32 s26, 0x1fffffff"] + [f"s_mov_b32 s{16 + j}, 0x{P[j]:08x}" for j in range(9)]
+    x = gen_f29(square, col=2, m0=4, out0=0, a0=18, b0=27, consts=False)
+    y = gen_f29(square, col=14, m0=16, out0=9, a0=36, b0=45, consts=False)
+    body = []
+    for i in range(max(len(x), len(y))):
+        if i < len(x):
+            body.append(x[i])
+        if i < len(y):
+            body.append(y[i])
+    return head + body + ["s_nop 1"]
+
+
+def simulate_f29(ins_list, operands, n_out=9):
+    """interprets a 29-bit stream on Python integers; operands: {operand index: value}; returns the list of result operands %0..%{n_out-1}"""
+    import re
+    reg = {f"%{k}": v for k, v in operands.items()}
+
+    def val(tok):
+        tok = tok.strip()
+        if tok.startswith("0x"):
+            return int(tok, 16)
+        if tok.isdigit():
+            return int(tok)
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return reg.get(f"v{m.group(1)}", 0) | (reg.get(f"v{m.group(2)}", 0) << 32)
+        return reg[tok]
+
+    def put64(tok, r):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        reg[f"v{m.group(1)}"] = r & 0xFFFFFFFF; reg[f"v{m.group(2)}"] = r >> 32
+    for text in ins_list:
+        op, rest = text.split(" ", 1)
+        args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)]
+        if op in ("s_mov_b32", "v_mov_b32_e32"):
+            reg[args[0]] = val(args[1]) & 0xFFFFFFFF
+        elif op == "v_mad_u64_u32":
+            r = val(args[2]) * val(args[3]) + val(args[4])
+            assert r < 1 << 64, "column overflow"
+            put64(args[0], r)
+        elif op == "v_mul_lo_u32":
+            reg[args[0]] = (val(args[1]) * val(args[2])) & 0xFFFFFFFF
+        elif op == "v_and_b32_e32":
+            reg[args[0]] = val(args[1]) & val(args[2])
+        elif op == "v_lshrrev_b64":
+            put64(args[0], val(args[2]) >> val(args[1]))
+        elif op == "s_nop":
+            pass
+        else:
+            raise ValueError(op)
+    return [reg[f"%{j}"] for j in range(n_out)]
+
+
+def selftest_f29():
+    import random
+    rnd = random.Random(29)
+    q = F29_P
+    rinv = pow(1 << 261, -1, q)
+    limbs = lambda x: [(x >> (29 * i)) & ((1 << 29) - 1) if i < 8 else x >> 232 for i in range(9)]
+    value = lambda l: sum(x << (29 * i) for i, x in enumerate(l))
+    ops = lambda base, l: {base + i: x for i, x in enumerate(l)}
+    mul, sqr, mul2, sqr2 = gen_f29(False), gen_f29(True), gen_f29_dual(False), gen_f29_dual(True)
+    for t in range(300):
+        a = rnd.randrange(13 * q) if t > 3 else [0, 1, q - 1, 13 * q - 1][t]
+        b = rnd.randrange(13 * q) if t > 3 else [0, q - 1, q - 1, 13 * q - 1][t]
+        got = value(simulate_f29(mul, {**ops(9, limbs(a)), **ops(18, limbs(b))}))
+        assert got < 2 * q and got % q == a * b * rinv % q, ("mul", t)
+        # unnormalised operand: limbs up to 2^30.6 on one side (a difference a + S - b as the mixed addition feeds it)
+        big = [min(x + (3 << 28), (1 << 31) - 1) for x in limbs(a % (4 * q))]
+        got = value(simulate_f29(mul, {**ops(9, big), **ops(18, limbs(b % (2 * q)))}))
+        assert got % q == value(big) * (b % (2 * q)) * rinv % q, ("mul-unnormalised", t)
+        a8 = a % (8 * q)
+        got = value(simulate_f29(sqr, {**ops(9, limbs(a8)), **ops(18, [2 * x for x in limbs(a8)])}))
+        assert got < 2 * q and got % q == a8 * a8 * rinv % q, ("sqr", t)
+        # the interleaved pairs: two independent results, each equal to its single stream's
+        c, d = rnd.randrange(8 * q), rnd.randrange(8 * q)
+        r = simulate_f29(mul2, {**ops(18, limbs(a8)), **ops(27, limbs(b % (8 * q))), **ops(36, limbs(c)), **ops(45, limbs(d))}, 18)
+        assert value(r[:9]) % q == a8 * (b % (8 * q)) * rinv % q and value(r[9:]) % q == c * d * rinv % q and value(r[:9]) < 2 * q and value(r[9:]) < 2 * q, ("mul2", t)
+        r = simulate_f29(sqr2, {**ops(18, limbs(a8)), **ops(27, [2 * x for x in limbs(a8)]), **ops(36, limbs(c)), **ops(45, [2 * x for x in limbs(c)])}, 18)
+        assert value(r[:9]) % q == a8 * a8 * rinv % q and value(r[9:]) % q == c * c * rinv % q, ("sqr2", t)
+    print("selftest ok: 29-bit product / squaring streams (single and interleaved pairs) == a*b*2^-261 mod q, no column overflow")
+
+
 def simulate(ins_list, a, b):
     """Interprets the generated stream on Python ints (one lane).  Returns the 8 result limbs."""
     import re
@@ -293,3 +457,4 @@ if __name__ == "__main__":
     if "--check" in sys.argv:
         selftest()
         selftest_addsub()
+        selftest_f29()

@@ -2,8 +2,8 @@
 libsnark_trusted_setup ("issuer"), libsnark_prove ("prover") and libsnark_verify ("verifier") on a zklaim_ctx and record the
 pk / vk / proof sizes — same CSV columns as the reference writes (main_benchmark.c:158-165), but WALL-CLOCK milliseconds: the
 reference's CLOCK_THREAD_CPUTIME_ID (main_benchmark.c:113-117) does not see time spent waiting on the GPU.
-prover_ms is the mean of 5 libsnark_prove calls on the resident key after 3 warm-up calls (the first calls on a new key grow the
-runtime's per-stream pools); first_prove_ms is the very first call, which parses the pk blob, decompresses it on the GPU and uploads.
+prover_ms is what the reference's harness times (main_benchmark.c:136-140): the ONE libsnark_prove call that follows libsnark_trusted_setup
+on a fresh key.  prover_resident_ms is the mean of 5 further calls on the same (by then long-resident) key after 3 unmeasured ones.
 Usage: python tools/zklaim_benchmark.py [k ...]   (default 1..20 payloads and --runs 30, as main_benchmark.c:175-182)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ cli = ap.parse_args()
 ks = cli.ks or list(range(1, 21))
 RUNS = cli.runs
 zkg.init(0)
-print("time,k,issuer_ms,prover_ms,verifier_ms,pk_B,vk_B,proof_B,constraints,first_prove_ms_incl_key_upload,domain_m,domain_kind")
+print("time,k,issuer_ms,prover_ms,verifier_ms,pk_B,vk_B,proof_B,constraints,prover_resident_ms,domain_m,domain_kind")
 for k in ks:
     for run in range(RUNS):
         keep = []
@@ -27,7 +27,9 @@ for k in ks:
         ctx = zkg.make_ctx(pls, keep)
         t0 = time.perf_counter(); rc = zkg.libsnark_trusted_setup(ctx); t_issuer = time.perf_counter() - t0
         assert rc == 0
-        t0 = time.perf_counter(); rc = zkg.libsnark_prove(ctx); t_first = time.perf_counter() - t0      # includes pk blob parse + GPU decompression + upload
+        t0 = time.perf_counter(); rc = zkg.libsnark_prove(ctx); t_first = time.perf_counter() - t0      # the protocol's prove: first call on the key just generated
+        assert rc == 0
+        t0 = time.perf_counter(); rc = zkg.libsnark_verify(ctx); t_verifier = time.perf_counter() - t0   # verifies the proof of that first call
         assert rc == 0
         for _ in range(3):
             assert zkg.libsnark_prove(ctx) == 0
@@ -36,11 +38,9 @@ for k in ks:
             rc = zkg.libsnark_prove(ctx)                                                                # resident key
         t_prover = (time.perf_counter() - t0) / 5
         assert rc == 0
-        t0 = time.perf_counter(); rc = zkg.libsnark_verify(ctx); t_verifier = time.perf_counter() - t0
-        assert rc == 0
         r1 = zkg.ZklaimCircuit(ctx, with_witness=False).r1cs
         ncons = r1.num_constraints
         m, is_step = zkg.evaluation_domain_size(ncons + r1.num_inputs + 1)
-        print(f"{int(time.time())},{k},{t_issuer*1e3:.1f},{t_prover*1e3:.2f},{t_verifier*1e3:.2f},{ctx.pk_size},{ctx.vk_size},{ctx.proof_size},{ncons},{t_first*1e3:.1f},"
+        print(f"{int(time.time())},{k},{t_issuer*1e3:.1f},{t_first*1e3:.2f},{t_verifier*1e3:.2f},{ctx.pk_size},{ctx.vk_size},{ctx.proof_size},{ncons},{t_prover*1e3:.2f},"
               f"{m},{'step_radix2' if is_step else 'basic_radix2'}", flush=True)
         zkg.lib().zkg_compat_reset()

@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = [
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
-    "zkg_msm_g1_multi",
+    "zkg_msm_g1_multi", "zkg_g1_add_quad29",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -112,12 +112,20 @@ def device_info():
 
 
 def field_op(field, op, a, b=None):
-    """element-wise device arithmetic (zkg_field_op): field 0 Fq, 1 Fr, 2 Fq2; op 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr"""
+    """element-wise device arithmetic (zkg_field_op): field 0 Fq, 1 Fr, 2 Fq2; op 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr;
+    Fq only: 10-14 the 29-bit representation of the accumulation kernel (mul, add, sub, zero test, composite)"""
     a = _u64(a); limbs = 8 if field == 2 else 4
     out = np.zeros_like(a)
     bb = None if b is None else _u64(b)
     _check(lib().zkg_field_op(int(field), int(op), _p(a), _p(bb), C.c_size_t(a.size // limbs), _p(out)), "zkg_field_op")
     return out
+
+
+def g1_add_quad29(a_jac, b_jac, chain=0):
+    """out[i] = a[i] + b[i] (then `chain` rounds of x <- 2x + b[i]) on the GPU through the 29-bit quad addition of the reduction kernels"""
+    a = _u64(a_jac); b = _u64(b_jac); out = np.zeros_like(a)
+    _check(lib().zkg_g1_add_quad29(_p(a), _p(b), C.c_size_t(a.size // 12), int(chain), _p(out)), "zkg_g1_add_quad29")
+    return out.reshape(-1, 12)
 
 
 # ---- NTT (libfqfft basic_radix2_domain FFT/iFFT/cosetFFT/icosetFFT) -------------------------------

@@ -4,6 +4,7 @@
 // points sit directly below r1cs_gg_ppzksnark_prover (/root/reference/zklaim/snark.cpp:126).
 // There is no CPU fallback: every entry point fails with ZKG_ERROR when no HIP device is usable.
 #include "common.hpp"
+#include "fq29.hip.hpp"
 #include "../../include/zkg.h"
 #include <atomic>
 #include <condition_variable>
@@ -161,6 +162,23 @@ template <class F> __global__ __launch_bounds__(64) void k_field_op(int op, cons
         if (op == 4) { out[i] = x.to_mont().normalized(); return; }
         if (op == 5) { out[i] = x.from_mont(); return; }
     }
+    if constexpr (std::is_same<F, Fq>::value) {
+        // the 29-bit representation of the accumulation kernel (fq29.hip.hpp), entered and left through its own conversions
+        if (op >= 10 && op <= 14) {
+            const Fq29 xa = f29::to29(x), yb = f29::to29(y);
+            Fq29 r = xa;
+            if (op == 10) r = f29::mul(xa, yb);
+            else if (op == 11) r = f29::norm(f29::add(xa, yb));
+            else if (op == 12) r = f29::norm(f29::sub(xa, f29::S2_1, yb));
+            else if (op == 14) {                 // a chain as the mixed addition builds them: unnormalised differences into products
+                const Fq29 d = f29::sub(xa, f29::S6_1, yb), e = f29::norm(f29::sub(yb, f29::S4_1, xa));
+                r = f29::norm(f29::sub(f29::mul(e, d), f29::S4_3, f29::add(f29::mul(e, e), f29::dbl(f29::mul(xa, yb)))));      // (b-a)(a-b) - (b-a)^2 - 2ab
+            }
+            Fq o = f29::from29(r);
+            if (op == 13 && f29::is_zero_mod_p(f29::norm(f29::sub(xa, f29::S2_1, yb)))) o = Fq::zero();                          // zero test: out = 0 iff a == b
+            out[i] = o; return;
+        }
+    }
     out[i] = field_apply(op, x, y).normalized();
 }
 template <class F> static int field_op_run(int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
@@ -177,11 +195,27 @@ template <class F> static int field_op_run(int op, const uint64_t *a, const uint
     return rc;
 }
 
+// known-answer hook for the 29-bit group law of the reduction kernels (fq29.hip.hpp xyzz29_add_quad): out[i] = a[i] + b[i], one DPP quad
+// per pair, points as XYZZ<Fq> in and out (converted by the same quad_load29 / from29 the kernels use)
+__global__ __launch_bounds__(64) void k_add_quad29(const XYZZ<Fq> *a, const XYZZ<Fq> *b, size_t n, int chain, XYZZ<Fq> *out) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; const uint32_t q = threadIdx.x & 3;
+    if (i >= n) return;
+    const XYZZ<Fq> pa = a[i], pb = b[i];
+    XYZZ29q x = pa.is_inf() ? XYZZ29q::inf() : quad_load29(pa.x, pa.y, pa.zz, pa.zzz, q);
+    const XYZZ29q y = pb.is_inf() ? XYZZ29q::inf() : quad_load29(pb.x, pb.y, pb.zz, pb.zzz, q);
+    if (chain < 0) xyzz29_add_lane(x, y); else
+    xyzz29_add_quad(x, y, q);
+    for (int k = 0; k < chain; ++k) { XYZZ29q z = x; xyzz29_add_quad(x, y, q); xyzz29_add_quad(x, z, q); }     // sums of sums: the invariants across additions
+    if (q == 0) out[i] = x.is_inf() ? XYZZ<Fq>::inf().normalized() : XYZZ<Fq>{f29::from29(x.x), f29::from29(x.y), f29::from29(x.zz), f29::from29(x.zzz)};
+}
+
 static std::mutex g_init_mu;
 static int g_device = -1;
 static void kernels_configure() { (void)ntt_configure(); (void)msm_configure(); }
 
 }  // namespace zk
+
+void seam_keygen_quiesce();          // setup_verify.hip
 
 using namespace zk;
 
@@ -198,6 +232,7 @@ int zkg_init(int device) {
     return ZKG_OK;
 }
 void zkg_shutdown(void) {
+    seam_keygen_quiesce();
     std::lock_guard<std::mutex> lk(g_init_mu);
     if (g_device < 0) return;
     (void)hipDeviceSynchronize();
@@ -329,6 +364,23 @@ int zkg_g1_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[12]) {
     store_norm(out_jac, acc);
     return ZKG_OK;
 }
+// out[i] = a[i] + b[i] (then `chain` rounds of x <- 2x + b) on the GPU through the 29-bit quad addition; normalised Jacobian in and out
+int zkg_g1_add_quad29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac) {
+    REQUIRE_INIT();
+    if (!a_jac || !b_jac || !out_jac || chain < -1 || chain > 64) { set_error("zkg_g1_add_quad29: bad argument"); return ZKG_ERROR; }
+    if (!n) return ZKG_OK;
+    std::vector<G1> ha(n), hb(n), ho(n);
+    for (size_t i = 0; i < n; ++i) { ha[i] = load_norm_g1(a_jac + 12 * i).normalized(); hb[i] = load_norm_g1(b_jac + 12 * i).normalized(); }
+    ScopedDevBuf da, db, dout;
+    if (da.reserve(n * sizeof(G1)) || db.reserve(n * sizeof(G1)) || dout.reserve(n * sizeof(G1))) return ZKG_ERROR;
+    ZK_HIP(hipMemcpy(da.p, ha.data(), n * sizeof(G1), hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(db.p, hb.data(), n * sizeof(G1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_add_quad29, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, nullptr, da.as<G1>(), db.as<G1>(), n, chain, dout.as<G1>());
+    if (hipGetLastError() != hipSuccess) { set_error("zkg_g1_add_quad29: launch failed"); return ZKG_ERROR; }
+    ZK_HIP(hipMemcpy(ho.data(), dout.p, n * sizeof(G1), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) store_norm(out_jac + 12 * i, ho[i]);
+    return ZKG_OK;
+}
 int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]) {
     G2 acc = G2::inf();
     for (size_t i = 0; i < count; ++i) acc.add(load_norm_g2(points_jac + 24 * i));
@@ -349,7 +401,7 @@ int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t
 
 int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
     REQUIRE_INIT();
-    const bool binary = op >= 0 && op <= 2, known = binary || op == 3 || op == 6 || op == 7 || ((op == 4 || op == 5) && field != 2);
+    const bool binary = (op >= 0 && op <= 2) || (op >= 10 && op <= 14 && field == 0), known = binary || op == 3 || op == 6 || op == 7 || ((op == 4 || op == 5) && field != 2);
     if (!known || field < 0 || field > 2 || !a || !out || (binary && !b)) { set_error("zkg_field_op: bad argument"); return ZKG_ERROR; }
     if (!n) return ZKG_OK;
     if (field == 0) return field_op_run<Fq>(op, a, binary ? b : nullptr, n, out);

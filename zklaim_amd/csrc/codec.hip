@@ -129,6 +129,50 @@ static int decompress_dev(K kernel, const uint8_t *host_rec, size_t stride, size
     return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
 
+// ---- the other direction: affine points on the device -> the blob's compressed records (libsnark_export_pk's operator<<,
+//      /root/reference/zklaim/libsnark_wrapper.cpp:146-157).  The seam's key generator leaves its ~4n + m points on the device (they are the
+//      resident key of the proofs that follow) and only these records — 34 / 100 bytes instead of 64 / 192 — travel to the host.
+//      A workgroup assembles its 256 records in LDS (byte stores) and writes them out as whole words: a run of records starts 16-byte
+//      aligned in the staging buffer and 256 records are a multiple of four bytes.
+ZK_D void put_fq_bytes(uint8_t *p, const Fq &x) {
+    for (int i = 0; i < 8; ++i) { p[4 * i] = (uint8_t)x.v[i]; p[4 * i + 1] = (uint8_t)(x.v[i] >> 8); p[4 * i + 2] = (uint8_t)(x.v[i] >> 16); p[4 * i + 3] = (uint8_t)(x.v[i] >> 24); }
+}
+ZK_D void put_g1_record(uint8_t *o, const G1Affine &a) {                  // ser::put_g1
+    const bool inf = a.is_inf();
+    const Fq x = inf ? Fq::zero() : a.x.normalized(), y = inf ? Fq::one() : a.y;
+    o[0] = inf ? '1' : '0'; put_fq_bytes(o + 1, x); o[33] = (y.from_mont().v[0] & 1u) ? '1' : '0';
+}
+ZK_D void put_g2_record(uint8_t *o, const G2Affine &a) {                  // ser::put_g2
+    const bool inf = a.is_inf();
+    const Fq2 x = inf ? Fq2::zero() : a.x.normalized(); const Fq y0 = inf ? Fq::one() : a.y.c0;
+    o[0] = inf ? '1' : '0'; put_fq_bytes(o + 1, x.c0); put_fq_bytes(o + 33, x.c1); o[65] = (y0.from_mont().v[0] & 1u) ? '1' : '0';
+}
+// REC = 34: record i = G1 in1[i].  REC = 100: record j = G2 in2[idx[j]] then G1 in1[idx[j]] (a knowledge commitment of the sparse B query)
+template <int REC>
+__global__ __launch_bounds__(256) void k_compress_records(const G1Affine *in1, const G2Affine *in2, const uint32_t *idx, size_t n, uint8_t *out) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[256 * REC];
+    const size_t first = (size_t)blockIdx.x * 256, i = first + threadIdx.x;
+    if (i < n) {
+        uint8_t *o = stage + (size_t)threadIdx.x * REC;
+        if constexpr (REC == 34) put_g1_record(o, in1[i]);
+        else { const uint32_t e = idx[i]; put_g2_record(o, in2[e]); put_g1_record(o + 66, in1[e]); }
+    }
+    __syncthreads();
+    const size_t bytes = (n - first < 256 ? n - first : 256) * REC;         // this block's run; its start, first * REC, is a multiple of 4
+    uint8_t *dst = out + first * REC;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(stage);
+    for (size_t k = threadIdx.x; k < bytes / 4; k += 256) reinterpret_cast<uint32_t *>(dst)[k] = w[k];
+    for (size_t k = (bytes & ~(size_t)3) + threadIdx.x; k < bytes; k += 256) dst[k] = stage[k];
+}
+int compress_g1_records(const G1Affine *d_in, size_t n, uint8_t *d_out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_compress_records<34>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (const G2Affine *)nullptr, (const uint32_t *)nullptr, n, d_out);
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+int compress_kc_records(const G2Affine *d_g2, const G1Affine *d_g1, const uint32_t *d_idx, size_t nidx, uint8_t *d_out, hipStream_t s) {
+    if (nidx) hipLaunchKernelGGL(k_compress_records<100>, dim3((unsigned)((nidx + 255) / 256)), dim3(256), 0, s, d_g1, d_g2, d_idx, nidx, d_out);
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+
 }  // namespace zk
 
 using namespace zk;

@@ -108,10 +108,13 @@ static constexpr int MSM_MAX_SETS = 4;                      // base sets sharing
 // scalars stands for element i - index_sub of the set (the L query starts behind the constant and the public inputs); smaller i: no base.
 // remap (optional, device): element i of the scalars stands for entry remap[i] of the set — a table that holds only a subset of the key's
 // elements (the prover's witness tables cover the non-bit variables only).
-struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; const uint32_t *remap = nullptr; };
+// p29 (optional, G1 only): the same points, every level, as the 80-byte 29-bit records of fq29.hip.hpp (window_table_records29): a launch of
+// this set alone, without gather / remap / index_sub, then accumulates on the 29-bit representation without converting anything per call.
+struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; const uint32_t *remap = nullptr; const void *p29 = nullptr; };
 // CSR matrices A, B, C handed from a circuit to the key generator without a copy
 struct OwnedCsr { std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val[3]; };
-struct WindowTable { DevBuf buf; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); n = 0; } };
+struct WindowTable { DevBuf buf, rec29; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); rec29.release(); n = 0; } };
+int window_table_records29(WindowTable &t, hipStream_t s);                // rec29 <- every level of a built G1 table as 29-bit records
 int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s);
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s);
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
@@ -155,6 +158,12 @@ int fixed_base_g1(const G1Affine &base, const uint32_t *d_scalars, size_t n, G1A
 int fixed_base_g2(const G2Affine &base, const uint32_t *d_scalars, size_t n, G2Affine *d_out, hipStream_t s, bool scalars_mont = false);
 void msm_release_all();
 int msm_configure();
+
+// ---------------- key blobs (codec.hip) ----------------
+// affine points on the device -> the pk blob's compressed records (34 bytes per G1; 100 per knowledge commitment G2 | G1 of the sparse
+// B query, entry idx[j]); d_out: 16-byte aligned device staging for n x 34 (nidx x 100) bytes
+int compress_g1_records(const G1Affine *d_in, size_t n, uint8_t *d_out, hipStream_t s);
+int compress_kc_records(const G2Affine *d_g2, const G1Affine *d_g1, const uint32_t *d_idx, size_t nidx, uint8_t *d_out, hipStream_t s);
 
 // ---------------- ABI encodings (capi.cpp) ----------------
 void store_norm(uint64_t *out, const G1 &p);   // normalised jac, 12 limbs

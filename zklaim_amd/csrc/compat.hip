@@ -34,7 +34,9 @@ size_t zkg_keypair_vk_blob(const zkg_keypair *kp, uint8_t *out, size_t cap);
 int zkg_groth16_verify(const uint8_t *vk_blob, size_t vk_len, const uint64_t *primary_input, size_t n_inputs, const uint8_t *proof, size_t proof_len);
 }
 
-zkg_keypair *groth16_setup_owned(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu);    // setup_verify.hip
+int seam_keygen(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu, unsigned char **pk_out, size_t *pk_len,
+                unsigned char **vk_out, size_t *vk_len, zkg_crs **crs_out, const std::function<void(const unsigned char *, size_t)> &on_blob);    // setup_verify.hip
+void seam_keygen_quiesce();                                                                                              // setup_verify.hip
 void circuit_release_csr(zkg_circuit *c, zk::OwnedCsr &out);                                                            // zklaim_circuit.hip
 
 namespace {
@@ -125,30 +127,50 @@ static int libsnark_trusted_setup_impl(zklaim_ctx *ctx) {
     if (!ck) return ZKLAIM_ERROR;
     lap("circuit built");
     zkg_r1cs cs;
-    zkg_keypair *kp = nullptr;
-    if (zkg_circuit_r1cs(ck, &cs) == 0) {
-        // the keypair takes the circuit's CSR matrices over (no copy), and what is left of the circuit — the constraint arena and the
-        // variable store — is destroyed on a side thread while the GPU turns the generator's scalars into points
-        zk::OwnedCsr csr;
-        circuit_release_csr(ck, csr);
-        cs.a_rowptr = cs.b_rowptr = cs.c_rowptr = nullptr; cs.a_col = cs.b_col = cs.c_col = nullptr; cs.a_val = cs.b_val = cs.c_val = nullptr;
-        bool freed = false;
-        kp = groth16_setup_owned(&cs, &csr, [&] { zkg_circuit_free(ck); freed = true; });
-        if (!freed) zkg_circuit_free(ck);                        // the generator failed before its GPU phase
-    } else zkg_circuit_free(ck);
-    if (!kp) return ZKLAIM_ERROR;
-    lap("keypair generated");
-    size_t vk_len = zkg_keypair_vk_blob(kp, nullptr, 0), pk_len = zkg_keypair_pk_blob(kp, nullptr, 0);
-    unsigned char *vk = (unsigned char *)malloc(vk_len), *pk = (unsigned char *)malloc(pk_len);
-    int rc = ZKLAIM_ERROR;
-    if (vk && pk && zkg_keypair_vk_blob(kp, vk, vk_len) == vk_len && zkg_keypair_pk_blob(kp, pk, pk_len) == pk_len) {
-        ctx->vk = vk; ctx->vk_size = vk_len; ctx->pk = pk; ctx->pk_size = pk_len;                 // libsnark_wrapper.cpp:207-208
-        rc = ZKLAIM_OK;
-    } else { free(vk); free(pk); }
-    lap("blobs written");
-    zkg_keypair_free(kp);                                  // (in the caller's time on purpose: handing half a GB back to the allocator on another thread
-                                                           // made the call 30 ms shorter and the prove that follows it 60 ms longer)
-    return rc;
+    if (zkg_circuit_r1cs(ck, &cs) != 0) { zkg_circuit_free(ck); return ZKLAIM_ERROR; }
+    // the generator takes the circuit's CSR matrices over (no copy), and what is left of the circuit — the constraint arena and the
+    // variable store — is destroyed on a side thread while the GPU turns the generator's scalars into points
+    zk::OwnedCsr csr;
+    circuit_release_csr(ck, csr);
+    cs.a_rowptr = cs.b_rowptr = cs.c_rowptr = nullptr; cs.a_col = cs.b_col = cs.c_col = nullptr; cs.a_val = cs.b_val = cs.c_val = nullptr;
+    bool freed = false;
+    unsigned char *pk = nullptr, *vk = nullptr; size_t pk_len = 0, vk_len = 0; zkg_crs *crs = nullptr;
+    uint64_t key = 0; Digest128 full;
+    // the reference's protocol proves with the key it has just generated (main_benchmark.c:113-140): the generator's points stay on the GPU
+    // as that key, already resident when libsnark_prove looks ctx->pk up — by the digests of the very bytes handed to the caller
+    const int rc_gen = seam_keygen(&cs, &csr, [&] { zkg_circuit_free(ck); freed = true; }, &pk, &pk_len, &vk, &vk_len, &crs,
+                                   [&](const unsigned char *blob, size_t len) { key = sampled_digest(blob, len); full = full_digest(blob, len); });
+    if (!freed) zkg_circuit_free(ck);                            // the generator failed before its GPU phase
+    if (rc_gen != ZKG_OK) return ZKLAIM_ERROR;
+    lap("keys generated");
+    ctx->vk = vk; ctx->vk_size = vk_len; ctx->pk = pk; ctx->pk_size = pk_len;                     // libsnark_wrapper.cpp:207-208
+    std::shared_ptr<zkg_crs> shared = share_crs(crs);
+    static const bool no_warm = getenv("ZKG_SEAM_NO_WARM") != nullptr;
+    if (!no_warm) {
+        // Key preparation that needs a witness' SHAPE: which variables are not bits decides what the witness tables cover, and the first
+        // proof on a key allocates every stream's workspace.  The ctx at hand names a credential of exactly this shape (the issuer's
+        // own, in the reference's flow the very one proved next), so one proof is run on it and thrown away; a ctx without pre-images
+        // still has the shape.  Failure here is not an error of the setup: the first real proof then does this work itself.
+        zkg_circuit *wk = zkg_zklaim_witness_new(ctx);
+        const uint8_t *tags = nullptr; const uint32_t *fidx = nullptr; const uint64_t *fval = nullptr; size_t nfull = 0;
+        if (wk && zkg_circuit_sparse_witness(wk, &tags, &fidx, &fval, &nfull) == ZKG_OK && zkg_circuit_num_variables(wk) == zkg_crs_num_variables(crs)) {
+            uint64_t r[4], s2[4]; unsigned char scratch[ZKG_PROOF_BYTES]; size_t len = 0;
+            random_fr_mont(r); random_fr_mont(s2);
+            (void)zkg_groth16_prove_sparse(crs, tags, fidx, fval, nfull, r, s2, 0, scratch, &len);
+        }
+        if (wk) zkg_circuit_free(wk);
+        lap("key warmed");
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_crs_cache.size() >= 4) g_crs_cache.clear();
+        auto entry = std::make_shared<CachedCrs>();
+        entry->size = pk_len; entry->full = full; entry->crs = shared; entry->loading = false;
+        auto it = g_crs_cache.find(key);
+        if (it == g_crs_cache.end() || !it->second->loading) g_crs_cache[key] = entry;
+    }
+    lap("key resident");
+    return ZKLAIM_OK;
 }
 int libsnark_trusted_setup(zklaim_ctx *ctx) {
     try { return libsnark_trusted_setup_impl(ctx); }                      // nothing propagates through the C boundary
@@ -274,6 +296,7 @@ int libsnark_verify(zklaim_ctx *ctx) {
 
 // drops the resident keys cached by libsnark_prove (tests / long-running hosts)
 void zkg_compat_reset(void) {
+    seam_keygen_quiesce();                                       // a finished generator's keypair may still be on its way back to the allocators
     std::lock_guard<std::mutex> lk(g_mu);
     g_crs_cache.clear();                                         // (a key still proving lives on until that proof returns)
 }

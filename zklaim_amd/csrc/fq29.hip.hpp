@@ -1,0 +1,263 @@
+// fq29.hip.hpp — alt_bn128 Fq in 9 limbs of 29 bits for the multi-exponentiation's accumulation kernel (device only).
+//
+// Replaces libff's Fp_model<4, alt_bn128_modulus_q>::mul_reduce on the hot path of multi_exp's bucket accumulation (reached from
+// r1cs_gg_ppzksnark_prover, /root/reference/zklaim/snark.cpp:126).  Same field, same values; only the register representation differs.
+//
+// Why: on gfx950 every VOP3-encoded vector instruction costs ~4.2 cycles per wavefront and every VOP2 one ~2.3
+// (profiles/r3_mul_variants.txt).  The 8 x 32-bit Montgomery product of fp.hip.hpp pays one v_mad_u64_u32 AND one v_addc_co_u32_e64
+// (the carry fold, VOP3 because its carry comes from an SGPR pair) per partial product: 1173 cycles.  With 29-bit limbs a 64-bit column
+// holds 18 partial products of 58 bits without overflowing, so there is no carry to fold: 162 multiply-adds, 9 quotient digits, 17 column
+// shifts — 895 cycles measured, and additions / subtractions are limb-wise VOP2 instructions without any carry chain.
+//
+// Representation.  R' = 2^261.  An element x is held as X = x R' mod p, as 9 limbs X = sum v[i] 2^(29 i).  "Digits": limbs 0..7 below
+// 2^29 (limb 8 holds the rest).  Values are NOT kept below p: a product's result is below p (1 + a b / (p R')) — below 2p whenever
+// a b < 169 p^2 — and sums / differences stay unreduced; every use site states the bound it relies on (in units of p) and the limb
+// bound that keeps a column sum below 2^64: 9 La Lb + 9 2^58 + 2^36 < 2^64 for operand limbs below La, Lb.
+// Subtraction a - b is a + S - b, limb-wise, with S a multiple of p written with every lower limb >= depth (2^29 - 1) ("spread": each limb
+// borrows `depth` units from the next), so that no limb goes negative for a subtrahend whose limbs are below depth 2^29 and whose value
+// is below (K - 1) p + ...: the constants S{K}_{depth} below.
+// Memory format stays libff's (8 x 32-bit limbs, R = 2^256, canonical): to29 / from29 convert with one product each.
+#pragma once
+#include "curve.hip.hpp"
+#include "f29_asm.inc"
+
+namespace zk {
+
+struct Fq29 {
+    uint32_t v[9];
+    static constexpr uint32_t M = (1u << 29) - 1;
+    static ZK_D Fq29 zero() { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = 0; return r; }
+};
+namespace f29 {
+// q, -q^-1 mod 2^29, q^-1 mod 2^29
+__device__ static constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+static constexpr uint32_t INV = 0x04866389u, PINV = 0x1b799c77u;
+// R' mod q (the element one); 32 R' mod q (to29: mont(X, TO) = 32 X = x 2^261 for X = x 2^256); 2^256 mod q (from29: mont(X', FROM) = x 2^256)
+__device__ static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+__device__ static constexpr uint32_t TO[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+__device__ static constexpr uint32_t FROM[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+// spread multiples of q: S{K}_{d} = K q with limbs 0..7 each increased by d 2^29 and the next limb decreased by d
+__device__ static constexpr uint32_t S2_1[9] = {0x30f9fa8eu, 0x2208c16cu, 0x38e5469du, 0x25aa45a0u, 0x2b0bb2efu, 0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
+__device__ static constexpr uint32_t S4_1[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu, 0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+__device__ static constexpr uint32_t S6_1[9] = {0x32edefaau, 0x261a4447u, 0x2aafd3d9u, 0x30fed0e4u, 0x212318cfu, 0x31238483u, 0x23e94785u, 0x3628e537u, 0x012259d5u};
+__device__ static constexpr uint32_t S4_3[9] = {0x61f3f51cu, 0x641182d8u, 0x71ca8d39u, 0x6b548b40u, 0x761765ddu, 0x6b6d02ffu, 0x629b8501u, 0x797098cdu, 0x00c19136u};
+
+// Montgomery product a b / R' mod q (generated stream, tools/gen_mont_asm.py gen_f29: one 64-bit column accumulator, 162 multiply-adds,
+// no carry folds).  Limbs: 9 La Lb < 2^63.8 (digits x digits, digits x one unnormalised sum or difference of digit vectors).
+// Values: a b < 169 p^2 gives a result below 2p.  Result: digits.
+// (As C++ — acc += (uint64_t) a_i * b_j — the compiler splits every column over two accumulators and joins them with a 64-bit add:
+//  895 cycles against ~830 for the stream; with one asm statement per multiply-add it pads each with s_nop.)
+ZK_D Fq29 mul(const Fq29 &a, const Fq29 &b) {
+    Fq29 t;
+    asm(ZK_F29_MUL_ASM
+        : "=&v"(t.v[0]), "=&v"(t.v[1]), "=&v"(t.v[2]), "=&v"(t.v[3]), "=&v"(t.v[4]), "=&v"(t.v[5]), "=&v"(t.v[6]), "=&v"(t.v[7]), "=&v"(t.v[8])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8])
+        : ZK_F29_CLOBBERS);
+    return t;
+}
+// a^2 / R' mod q: the 36 cross products once, against the doubled operand (a's limbs below 2^30: 4 (2 a_i) a_j + a_k^2 + 9 m p < 2^63)
+ZK_D Fq29 sqr(const Fq29 &a) {
+    Fq29 t; uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = a.v[i] << 1;
+    asm(ZK_F29_SQR_ASM
+        : "=&v"(t.v[0]), "=&v"(t.v[1]), "=&v"(t.v[2]), "=&v"(t.v[3]), "=&v"(t.v[4]), "=&v"(t.v[5]), "=&v"(t.v[6]), "=&v"(t.v[7]), "=&v"(t.v[8])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]),
+          "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8])
+        : ZK_F29_CLOBBERS);
+    return t;
+}
+// two independent products / squarings as ONE interleaved stream: r0 = a b, r1 = c d (r0 = a^2, r1 = c^2).  A lone product is a chain
+// of dependent multiply-adds; at the two wavefronts per SIMD the accumulation kernel runs at, their latency shows (measured: the single
+// stream no faster than the compiler's two-accumulator code).  The mixed addition's ten products come in five independent pairs.
+#define ZK_F29_OUT18(r0, r1) "=&v"(r0.v[0]), "=&v"(r0.v[1]), "=&v"(r0.v[2]), "=&v"(r0.v[3]), "=&v"(r0.v[4]), "=&v"(r0.v[5]), "=&v"(r0.v[6]), "=&v"(r0.v[7]), "=&v"(r0.v[8]), \
+                             "=&v"(r1.v[0]), "=&v"(r1.v[1]), "=&v"(r1.v[2]), "=&v"(r1.v[3]), "=&v"(r1.v[4]), "=&v"(r1.v[5]), "=&v"(r1.v[6]), "=&v"(r1.v[7]), "=&v"(r1.v[8])
+#define ZK_F29_IN9(a) "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8])
+ZK_D void mul2(Fq29 &r0, Fq29 &r1, const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d) {
+    asm(ZK_F29_MUL2_ASM : ZK_F29_OUT18(r0, r1) : ZK_F29_IN9(a.v), ZK_F29_IN9(b.v), ZK_F29_IN9(c.v), ZK_F29_IN9(d.v) : ZK_F29_CLOBBERS2);
+}
+ZK_D void sqr2(Fq29 &r0, Fq29 &r1, const Fq29 &a, const Fq29 &c) {
+    uint32_t da[9], dc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { da[i] = a.v[i] << 1; dc[i] = c.v[i] << 1; }
+    asm(ZK_F29_SQR2_ASM : ZK_F29_OUT18(r0, r1) : ZK_F29_IN9(a.v), ZK_F29_IN9(da), ZK_F29_IN9(c.v), ZK_F29_IN9(dc) : ZK_F29_CLOBBERS2);
+}
+// a + b, limb-wise (no carries; the caller's limb bound grows by the sum)
+ZK_D Fq29 add(const Fq29 &a, const Fq29 &b) { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+ZK_D Fq29 dbl(const Fq29 &a) { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] << 1; return r; }
+// a + S - b: S one of the spread constants above; b's limbs below depth 2^29 and b's value below what S's top limb covers
+ZK_D Fq29 sub(const Fq29 &a, const uint32_t (&S)[9], const Fq29 &b) { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + S[i] - b.v[i]; return r; }
+ZK_D Fq29 neg(const uint32_t (&S)[9], const Fq29 &b) { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = S[i] - b.v[i]; return r; }
+// carry propagation: the same value as digits (limbs 0..7 below 2^29).  Limbs below 2^32 on entry; the value below 2^261.
+ZK_D Fq29 norm(const Fq29 &a) {
+    Fq29 r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint32_t t = a.v[i] + c; r.v[i] = t & Fq29::M; c = t >> 29; }
+    r.v[8] = a.v[8] + c;
+    return r;
+}
+// is the value (digits, below 16 p) a multiple of q?  k = v[0] / q mod 2^29 would be that multiple: anything but 0..15 says no at once
+// (all but 2^-25 of the non-zero values); the rare candidates are compared limb by limb with k q.
+ZK_D bool is_zero_mod_p(const Fq29 &a) {
+    const uint32_t k = (a.v[0] * PINV) & Fq29::M;
+    if (__builtin_expect(k > 15, 1)) return false;
+    uint32_t diff = 0; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { c += (uint64_t)k * P[i]; const uint32_t d = i < 8 ? (uint32_t)c & Fq29::M : (uint32_t)c; diff |= d ^ a.v[i]; c >>= 29; }
+    return diff == 0;
+}
+// libff's memory form (canonical, R = 2^256, 8 x 32 bits) -> digits of x R' (value below 1.01 p), and back (canonical)
+ZK_D Fq29 unpack(const Fq &x) {
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, l = bit >> 5, s = bit & 31;
+        uint32_t lo = x.v[l] >> s;
+        if (s > 3 && l + 1 < 8) lo |= x.v[l + 1] << (32 - s);
+        r.v[i] = i < 8 ? lo & Fq29::M : lo;
+    }
+    return r;
+}
+ZK_D Fq29 to29(const Fq &x) { Fq29 t; for (int i = 0; i < 9; ++i) t.v[i] = TO[i]; return mul(unpack(x), t); }
+ZK_D Fq from29(const Fq29 &a) {            // a: digits, value below 13 p
+    Fq29 f; for (int i = 0; i < 9; ++i) f.v[i] = FROM[i];
+    const Fq29 t = mul(a, f);                // x 2^256 mod q, below 2q, digits
+    uint32_t w[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {            // 32-bit word l = bits [32 l, 32 l + 32)
+        const int i = (32 * l) / 29, s = 32 * l - 29 * i;
+        uint32_t v = t.v[i] >> s;
+        if (i + 1 < 9) v |= t.v[i + 1] << (29 - s);
+        if (s > 26 && i + 2 < 9) v |= t.v[i + 2] << (58 - s);
+        w[l] = v;
+    }
+    return Fq::reduce_once(w);
+}
+
+}  // namespace f29
+
+// a base point as the accumulation kernel gathers it: x, y as digits of x R', y R' (18 words), a flag word (1 = infinity) and padding to
+// 80 bytes, so that a point is five aligned 16-byte loads
+struct alignas(16) Affine29 { uint32_t x[9], y[9], inf, pad; };
+
+// XYZZ accumulator of the 29-bit path.  Value bounds kept between additions (units of p): X < 5.3, Y < 3.4, ZZ, ZZZ < 1.1; X and Y digits.
+struct XYZZ29 {
+    Fq29 x, y, zz, zzz;
+    // madd-2008-s on the 29-bit representation.  b: digits below 1.01 p, or a difference S2_1 - y (limbs below 2^30, value below 2p) for a
+    // negated point.  `inf` is the accumulator's infinity flag (kept in a register instead of a test of ZZ).  Returns false when the
+    // addition is one of the exceptional cases (b == +-accumulator): the caller handles those on the 32-bit path.
+    ZK_D bool madd(const Fq29 &bx, const Fq29 &by, bool &inf) {
+        using namespace f29;
+        if (inf) { x = bx; y = norm(by); for (int i = 0; i < 9; ++i) { zz.v[i] = ONE[i]; zzz.v[i] = ONE[i]; } inf = false; return true; }
+        Fq29 U2, S2; mul2(U2, S2, bx, zz, by, zzz);                         // < 1.02 each
+        const Fq29 Pd = norm(sub(U2, S6_1, x));                             // U2 - X1 + 6p   < 7.1      (x < 5.3: covered by 6p - 2^232)
+        const Fq29 Rd = norm(sub(S2, S4_1, y));                             // S2 - Y1 + 4p   < 5.1      (y < 3.4)
+        if (__builtin_expect(is_zero_mod_p(Pd), 0)) return false;
+        Fq29 PP, RR; sqr2(PP, RR, Pd, Rd);                                  // < 1 + 50.4 / 169 = 1.30;  < 1 + 26.1 / 169 = 1.16
+        Fq29 PPP, Q; mul2(PPP, Q, Pd, PP, x, PP);                           // < 1.06, < 1.05
+        const Fq29 D = add(PPP, dbl(Q));                                    // < 3.2, limbs below 3 2^29
+        x = norm(sub(RR, S4_3, D));                                         // RR - D + 4p    < 5.2
+        const Fq29 T = sub(Q, S6_1, x);                                     // Q - X3 + 6p    < 7.1, limbs below 2^30.6 (x digits)
+        Fq29 RT, YP; mul2(RT, YP, Rd, T, y, PPP);                           // < 1 + 36.3 / 169 = 1.22;  < 1.03
+        y = norm(sub(RT, S2_1, YP));                                        // RT - YP + 2p   < 3.3
+        Fq29 z2, z3; mul2(z2, z3, zz, PP, zzz, PPP);                        // < 1.01
+        zz = z2; zzz = z3;
+        return true;
+    }
+};
+
+// ---- general addition on the 29-bit representation, shared by the four lanes of a DPP quad (the bucket reduction's chains) ------------
+// Same scheme as xyzz_add_quad (curve.hip.hpp): the lanes hold identical copies of both operands, each multiplies a different pair and the
+// products are broadcast back — 14 dependent products become 4 rounds — but a round costs a 29-bit product: 930 cycles instead of 1293 at
+// the two wavefronts per SIMD these kernels run at, 951 instead of 1524 for a lone wavefront (profiles/r3_mul_variants.txt).
+// Invariants of a point (units of p): X < 5.3, Y < 3.4, ZZ, ZZZ < 1.1, all four digits; infinity: ZZ == 0 (all limbs).
+struct alignas(16) XYZZ29q {
+    Fq29 x, y, zz, zzz;
+    ZK_D bool is_inf() const { uint32_t o = 0; for (int i = 0; i < 9; ++i) o |= zz.v[i]; return o == 0; }
+    static ZK_D XYZZ29q inf() { XYZZ29q r; r.x = r.y = r.zz = r.zzz = Fq29::zero(); return r; }
+};
+// Broadcast of lane S of each quad.  STEP names the round of the addition (0 load, 1..4 the four product rounds); bit STEP of
+// ZK_F29_SHFL_MASK sends that round through ds_bpermute instead of a DPP move.  Round 4 does by default: with DPP moves there the sum came
+// out wrong on hardware (tests/test_gpu_field.py::test_g1_quad_addition_29bit_vs_oracle, bisected round by round with this mask; neither
+// wait states behind the product nor pinning the operands changed it), with ds_bpermute every case matches.  27 of them per addition.
+#ifndef ZK_F29_SHFL_MASK
+#define ZK_F29_SHFL_MASK 16
+#endif
+template <int S, int STEP = 0> ZK_D Fq29 quad_bcast29(const Fq29 &a) {
+    Fq29 r;
+    if constexpr ((ZK_F29_SHFL_MASK >> STEP) & 1) { for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], (int)((threadIdx.x & 60u) | S), 64); }
+    else { for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], S * 0x55, 0xf, 0xf, true); }
+    return r;
+}
+ZK_D Fq29 quad_select29(uint32_t q, const Fq29 &a0, const Fq29 &a1, const Fq29 &a2, const Fq29 &a3) {
+    Fq29 r;
+    for (int i = 0; i < 9; ++i) { uint32_t lo = q & 1 ? a1.v[i] : a0.v[i], hi = q & 1 ? a3.v[i] : a2.v[i]; r.v[i] = q & 2 ? hi : lo; }
+    return r;
+}
+// the point as the 32-bit kernels store it (canonical XYZZ<Fq>) -> 29-bit, one coordinate per lane of the quad, and back (lane-local)
+ZK_D XYZZ29q quad_load29(const Fq &x, const Fq &y, const Fq &zz, const Fq &zzz, uint32_t q) {
+    Fq mine;
+    for (int i = 0; i < 8; ++i) { uint32_t lo = q & 1 ? y.v[i] : x.v[i], hi = q & 1 ? zzz.v[i] : zz.v[i]; mine.v[i] = q & 2 ? hi : lo; }
+    const Fq29 c = f29::to29(mine);
+    XYZZ29q r = {quad_bcast29<0, 0>(c), quad_bcast29<1, 0>(c), quad_bcast29<2, 0>(c), quad_bcast29<3, 0>(c)};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(r.x.v[i]), "+v"(r.y.v[i]), "+v"(r.zz.v[i]), "+v"(r.zzz.v[i]));     // (executed here, quad active: see xyzz29_add_quad)
+    return r;
+}
+// the same addition by one lane (products in independent pairs); invariants as above
+ZK_D void xyzz29_add_lane(XYZZ29q &a, const XYZZ29q &b) {
+    using namespace f29;
+    if (b.is_inf()) return;
+    if (a.is_inf()) { a = b; return; }
+    Fq29 U1, U2, S1, S2; mul2(U1, U2, a.x, b.zz, b.x, a.zz); mul2(S1, S2, a.y, b.zzz, b.y, a.zzz);
+    const Fq29 P = norm(sub(U2, S2_1, U1)), R = norm(sub(S2, S2_1, S1));
+    if (__builtin_expect(is_zero_mod_p(P), 0)) {
+        if (is_zero_mod_p(R)) {
+            XYZZ<Fq> t = {from29(a.x), from29(a.y), from29(a.zz), from29(a.zzz)};
+            t = t.dbl();
+            a.x = to29(t.x.normalized()); a.y = to29(t.y.normalized()); a.zz = to29(t.zz.normalized()); a.zzz = to29(t.zzz.normalized());
+        } else a = XYZZ29q::inf();
+        return;
+    }
+    Fq29 PP, RR; sqr2(PP, RR, P, R);
+    Fq29 ZZ12, ZZZ12; mul2(ZZ12, ZZZ12, a.zz, b.zz, a.zzz, b.zzz);
+    Fq29 PPP, Q; mul2(PPP, Q, P, PP, U1, PP);
+    const Fq29 X3 = norm(sub(RR, S4_3, add(PPP, dbl(Q))));
+    const Fq29 T = sub(Q, S6_1, X3);
+    Fq29 RT, SP; mul2(RT, SP, T, R, PPP, S1);
+    a.x = X3; a.y = norm(sub(RT, S2_1, SP));
+    mul2(a.zz, a.zzz, ZZ12, PP, ZZZ12, PPP);
+}
+ZK_D void xyzz29_add_quad(XYZZ29q &a, const XYZZ29q &b, uint32_t q) {
+    using namespace f29;
+    if (b.is_inf()) return;                                   // quad-uniform branches: all four lanes see the same data
+    if (a.is_inf()) { a = b; return; }
+    const Fq29 m1 = mul(quad_select29(q, a.x, b.x, a.y, b.y), quad_select29(q, b.zz, a.zz, b.zzz, a.zzz));
+    const Fq29 U1 = quad_bcast29<0, 1>(m1), U2 = quad_bcast29<1, 1>(m1), S1 = quad_bcast29<2, 1>(m1), S2 = quad_bcast29<3, 1>(m1);      // < 1.04 each
+    const Fq29 P = norm(sub(U2, S2_1, U1)), R = norm(sub(S2, S2_1, S1));                                                      // < 3.1
+    if (__builtin_expect(is_zero_mod_p(P), 0)) {
+        if (is_zero_mod_p(R)) {                                // a == b: the doubling, on the 32-bit path (rare)
+            XYZZ<Fq> t = {from29(a.x), from29(a.y), from29(a.zz), from29(a.zzz)};
+            t = t.dbl();
+            a.x = to29(t.x.normalized()); a.y = to29(t.y.normalized()); a.zz = to29(t.zz.normalized()); a.zzz = to29(t.zzz.normalized());
+        } else a = XYZZ29q::inf();
+        return;
+    }
+    const Fq29 m2 = mul(quad_select29(q, P, R, a.zz, a.zzz), quad_select29(q, P, R, b.zz, b.zzz));
+    const Fq29 PP = quad_bcast29<0, 2>(m2), RR = quad_bcast29<1, 2>(m2), ZZ12 = quad_bcast29<2, 2>(m2), ZZZ12 = quad_bcast29<3, 2>(m2);  // < 1.06, 1.06, 1.01, 1.01
+    const Fq29 m3 = mul(quad_select29(q, P, U1, ZZ12, ZZ12), PP);           // lane 3 repeats lane 2's product
+    const Fq29 PPP = quad_bcast29<0, 3>(m3), Q = quad_bcast29<1, 3>(m3), ZZ3 = quad_bcast29<2, 3>(m3);                              // < 1.02, 1.01, 1.01
+    const Fq29 X3 = norm(sub(RR, S4_3, add(PPP, dbl(Q))));                  // RR - PPP - 2Q + 4p < 5.1
+    const Fq29 T = sub(Q, S6_1, X3);                                        // < 7.1, limbs below 2^30.6: one side of the next product
+    const Fq29 m4 = mul(quad_select29(q, T, PPP, PPP, PPP), quad_select29(q, R, S1, ZZZ12, ZZZ12));
+    a.x = X3; a.y = norm(sub(quad_bcast29<0, 4>(m4), S2_1, quad_bcast29<1, 4>(m4)));                                              // R T - S1 PPP + 2p < 3.2
+    a.zz = ZZ3; a.zzz = quad_bcast29<2, 4>(m4);
+    // The broadcasts above must execute HERE, with the whole quad active: a caller that only uses the sum in one lane of the quad
+    // (if (q == 0) store ...) otherwise lets the compiler sink these DPP moves into that branch, where lanes 1..3 are disabled and a
+    // DPP read of a disabled lane returns 0 (seen on hardware: the last round's Y and ZZZ wrong, everything else right).
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.y.v[i]), "+v"(a.zzz.v[i]));
+}
+
+}  // namespace zk

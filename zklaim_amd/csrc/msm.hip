@@ -39,6 +39,7 @@
 //     sets (A, B_g1, L) per launch (blockIdx.y).
 // Also here: the generator's fixed-base batch (k_fixed_table, k_fixed_base: byte windows, in-lane batched normalisation).
 #include "common.hpp"
+#include "fq29.hip.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
 #include <chrono>
@@ -465,18 +466,91 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, co
     }
     XYZZ<F> acc = XYZZ<F>::inf();
     if (k < end) {
-        uint32_t e = sorted[k];
+        // two loads deep (see k_bucket_accum29): the base of entry k + 1 and the index of entry k + 2 arrive under the addition of entry k
+        uint32_t e = sorted[k], e_next = k + 1 < end ? sorted[k + 1] : 0;
         Affine<F> p = bases.template load<PLAIN>(e, gb);
         while (true) {
             Affine<F> cur = p; uint32_t ce = e;
             ++k;
-            if (k < end) { e = sorted[k]; p = bases.template load<PLAIN>(e, gb); }        // prefetch the next base under this addition
+            if (k < end) { e = e_next; p = bases.template load<PLAIN>(e, gb); if (k + 1 < end) e_next = sorted[k + 1]; }
             if (ce & 1u) cur.y = cur.y.neg();
             acc.madd(cur);
             if (k >= end) break;
         }
     }
     buckets[gb] = acc.normalized();
+}
+
+// ---- 6'. the same accumulation for a plain G1 base set on the 29-bit representation (fq29.hip.hpp): 10 products of 895 cycles instead of
+//      1173 and carry-free additions per mixed addition.  The bases are converted once per launch into 80-byte records (k_bases_to29: two
+//      products per point against the 160 the point costs in the loop); an accumulator is converted back when its bucket is written, so
+//      everything downstream (heavy parts, fold, reduction, host) sees the same XYZZ<Fq> buckets as before.
+__global__ __launch_bounds__(256) void k_bases_to29(const Affine<Fq> *in, size_t n, Affine29 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<Fq> a = in[i];
+    const Fq29 x = f29::to29(a.x), y = f29::to29(a.y);
+    Affine29 o;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { o.x[j] = x.v[j]; o.y[j] = y.v[j]; }
+    o.inf = a.is_inf() ? 1u : 0u; o.pad = 0;
+    uint4 *dst = reinterpret_cast<uint4 *>(out + i); const uint4 *src = reinterpret_cast<const uint4 *>(&o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dst[j] = src[j];
+}
+ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
+    Affine29 o; const uint4 *src = reinterpret_cast<const uint4 *>(bases + (e >> 1)); uint4 *dst = reinterpret_cast<uint4 *>(&o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dst[j] = src[j];
+    return o;
+}
+// WAVES: wavefronts per SIMD the register allocation aims for (2: 204 registers, no spill; 3: 168 registers and a 232-byte spill frame)
+// level_stride != 0: `bases` is a per-window table (level w = 2^(c w) P_i, level_stride records apart) and a bucket reads its window's level
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+                                                         size_t lanes, XYZZ<Fq> *buckets, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= lanes) return;
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, L.buckets, 1);
+    const uint32_t gb = order[tid];
+    if (level_stride) bases += (size_t)(gb / B) * level_stride;
+    uint32_t k = offsets[gb], end = offsets[gb + 1];
+    if (end - k > heavy_t) {                                                    // as k_bucket_accum: long lists go to k_heavy_parts / k_heavy_merge
+        uint32_t nparts = (end - k + HEAVY_S - 1) / HEAVY_S;
+        uint32_t first = atomicAdd(&counters[0], nparts);
+        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb, nparts == 1}; }
+        if (nparts > 1) heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
+        return;
+    }
+    XYZZ29 acc; bool inf = true;
+    acc.x = acc.y = acc.zz = acc.zzz = Fq29::zero();
+    if (k < end) {
+        // two loads deep: under the addition of entry k the base of entry k + 1 arrives (its address came from an index loaded one
+        // addition earlier) and the index of entry k + 2 — neither the index nor the base is ever waited for right after it was requested
+        uint32_t e = sorted[k], e_next = k + 1 < end ? sorted[k + 1] : 0;
+        Affine29 p = load29(bases, e);
+        while (true) {
+            const Affine29 cur = p; const uint32_t ce = e;
+            ++k;
+            if (k < end) { e = e_next; p = load29(bases, e); if (k + 1 < end) e_next = sorted[k + 1]; }
+            if (!cur.inf) {
+                Fq29 bx, by;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { bx.v[j] = cur.x[j]; by.v[j] = cur.y[j]; }
+                if (ce & 1u) by = f29::neg(f29::S2_1, by);
+                if (__builtin_expect(!acc.madd(bx, by, inf), 0)) {
+                    // b == +-accumulator (a duplicated base under equal digits): the doubling / cancellation cases on the 32-bit path
+                    XYZZ<Fq> a32 = {f29::from29(acc.x), f29::from29(acc.y), f29::from29(acc.zz), f29::from29(acc.zzz)};
+                    a32.madd(Affine<Fq>{f29::from29(bx), f29::from29(f29::norm(by))});
+                    if (a32.is_inf()) inf = true;
+                    else { acc.x = f29::to29(a32.x.normalized()); acc.y = f29::to29(a32.y.normalized()); acc.zz = f29::to29(a32.zz.normalized()); acc.zzz = f29::to29(a32.zzz.normalized()); }
+                }
+            }
+            if (k >= end) break;
+        }
+    }
+    if (inf) buckets[gb] = XYZZ<Fq>::inf().normalized();
+    else buckets[gb] = XYZZ<Fq>{f29::from29(acc.x), f29::from29(acc.y), f29::from29(acc.zz), f29::from29(acc.zzz)};
 }
 
 // A point in LDS, padded to 144 B (G1) / 272 B (G2): at the natural 128 / 256-byte stride consecutive points start on the same four banks.
@@ -603,6 +677,66 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
         for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();            // * RED_L
         xyzz_add_quad(E, sh[RED_LANES].p, q);
         if (q == 0) { out[2 * (size_t)blockIdx.x] = P.normalized(); out[2 * (size_t)blockIdx.x + 1] = E.normalized(); }
+    }
+}
+
+// ---- 7'. the same reduction for G1 on the 29-bit representation (fq29.hip.hpp, xyzz29_add_quad): the kernel is a chain of dependent
+//      products at two wavefronts per SIMD, where a 29-bit product takes 930 cycles against 1293.  Buckets arrive as the accumulation wrote
+//      them (canonical XYZZ<Fq>) and are converted on load, one coordinate per lane of the quad; the two chunk results leave as XYZZ<Fq>.
+struct alignas(16) LdsPoint29 { XYZZ29q p; uint32_t pad[4]; };
+ZK_D XYZZ29q load_bucket29(const XYZZ<Fq> *X, uint32_t i, uint32_t B, uint32_t q) {
+    if (i >= B) return XYZZ29q::inf();
+    const XYZZ<Fq> b = X[i];
+    if (b.is_inf()) return XYZZ29q::inf();
+    return quad_load29(b.x, b.y, b.zz, b.zzz, q);
+}
+ZK_D XYZZ<Fq> store_point29(const XYZZ29q &p) {
+    if (p.is_inf()) return XYZZ<Fq>::inf().normalized();
+    return {f29::from29(p.x), f29::from29(p.y), f29::from29(p.zz), f29::from29(p.zzz)};
+}
+template <int RED_L_LOG>
+__global__ __launch_bounds__(RedGeom<Fq>::THREADS) void k_bucket_reduce29(const XYZZ<Fq> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
+                                                                          size_t in_set_stride, size_t out_set_stride) {
+    constexpr int RED_LANES = RedGeom<Fq>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
+    extern __shared__ unsigned char red_smem[];
+    LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * RED_LANES points
+    const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
+    const XYZZ<Fq> *X = buckets + blockIdx.y * in_set_stride + (size_t)w * B;
+    out += blockIdx.y * out_set_stride;
+    const uint32_t base = ch * RED_CHUNK + t * RED_L;
+    XYZZ29q run = XYZZ29q::inf(), T0 = XYZZ29q::inf();
+    XYZZ29q cur = load_bucket29(X, base + RED_L - 1, B, q);
+    for (int j = RED_L - 1; j >= 1; --j) {
+        const XYZZ29q nxt = load_bucket29(X, base + j - 1, B, q);
+        xyzz29_add_quad(run, cur, q);
+        xyzz29_add_quad(T0, run, q);
+        cur = nxt;
+    }
+    xyzz29_add_quad(run, cur, q);
+    XYZZ29q Q = run;                                                     // inclusive suffix scan of the lane sums over logical lanes
+    for (uint32_t d = 1; d < RED_LANES; d <<= 1) {
+        if (q == 0) sh[t].p = Q;
+        __syncthreads();
+        if (t + d < RED_LANES) xyzz29_add_quad(Q, sh[t + d].p, q);
+        __syncthreads();
+    }
+    const XYZZ29q P = Q;                                                 // logical lane 0: total of the chunk
+    if (q == 0) { sh[t].p = (t >= 1) ? Q : XYZZ29q::inf(); sh[RED_LANES + t].p = T0; }
+    __syncthreads();
+    for (uint32_t d = RED_LANES / 2; d >= 1; d >>= 1) {
+        if (t < d) { XYZZ29q a = sh[t].p; xyzz29_add_quad(a, sh[t + d].p, q); if (q == 0) sh[t].p = a; }
+        else if (t >= RED_LANES / 2 && t < RED_LANES / 2 + d) {
+            const uint32_t u = RED_LANES + (t - RED_LANES / 2);
+            XYZZ29q a = sh[u].p; xyzz29_add_quad(a, sh[u + d].p, q); if (q == 0) sh[u].p = a;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        XYZZ<Fq> E = store_point29(sh[0].p);
+        for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();                 // * RED_L (RED_L_LOG doublings, once per workgroup: the 32-bit path)
+        E.add(store_point29(sh[RED_LANES].p));
+        if (q == 0) { out[2 * (size_t)blockIdx.x] = store_point29(P); out[2 * (size_t)blockIdx.x + 1] = E.normalized(); }
     }
 }
 
@@ -739,6 +873,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uin
 // ---- jobs: one MSM (or several base sets over one scalar vector) in flight on one stream ---------------------
 struct MsmGroup {                   // the base sets of one field in a launch: accumulators and the host landing zone of their chunk results
     DevBuf buckets, folded, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
+    DevBuf bases29;                                    // a plain G1 set's bases as 80-byte 29-bit records (k_bases_to29), rebuilt per launch
     void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false; int nsets = 0;
     int out_index[MSM_MAX_SETS] = {0};                 // position of each set among the launch's sets of this field
     uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry per set: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
@@ -751,7 +886,7 @@ struct MsmGroup {                   // the base sets of one field in a launch: a
         return 0;
     }
     void release() {
-        for (DevBuf *b : {&buckets, &folded, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials}) b->release();
+        for (DevBuf *b : {&buckets, &folded, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials, &bases29}) b->release();
         if (host_red) (void)hipHostFree(host_red);
         host_red = nullptr; host_cap = 0;
     }
@@ -803,8 +938,33 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     const size_t lanes = gr.table ? std::min(total_buckets, n_entries_max) : total_buckets;
     bool plain = !d_gather;
     for (unsigned i = 0; i < ns; ++i) plain = plain && sets[i].level_stride == 0 && sets[i].index_sub == 0 && !sets[i].remap;
+    // a plain G1 set takes the 29-bit accumulation (ZKG_ACCUM_32: the 8 x 32-bit kernel, kept for A/B runs and for several sets per launch)
+    static const bool accum32 = getenv("ZKG_ACCUM_32") != nullptr;
+    bool use29 = false; const Affine29 *rec29 = nullptr; size_t stride29 = 0;
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        if (ns == 1 && !accum32 && plain) {
+            use29 = true;
+            if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+            hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+            rec29 = gr.bases29.as<Affine29>();
+        } else if (ns == 1 && !accum32 && !d_gather && sets[0].p29 && !sets[0].remap && sets[0].index_sub == 0) {
+            use29 = true; rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
+        }
+    }
     if (time_it) g_dominant_timer.begin(s);
-    if (plain)
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        static const int waves29 = getenv("ZKG_ACC29_WAVES") ? atoi(getenv("ZKG_ACC29_WAVES")) : 2;               // tuning aid
+        if (use29 && waves29 == 3)
+            hipLaunchKernelGGL(k_bucket_accum29<3>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
+                               job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(),
+                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
+        else if (use29)
+            hipLaunchKernelGGL(k_bucket_accum29<2>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
+                               job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(),
+                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
+    }
+    if (use29) {}
+    else if (plain)
         hipLaunchKernelGGL((k_bucket_accum<F, true>), dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
                            views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
                            gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
@@ -825,7 +985,20 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                            buckets, job->counts.as<uint32_t>(), g.W, g.B, fold_b_log, gr.folded.as<XYZZ<F>>(), L);
         red_in = gr.folded.as<XYZZ<F>>(); in_stride = L.folded;
     }
-    if (red_l_log == RED_L_LOG_LARGE)
+    bool reduce29 = false;
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        static const bool red32 = getenv("ZKG_REDUCE_32") != nullptr;                                     // A/B switch
+        reduce29 = !accum32 && !red32;
+        if (reduce29) {
+            const size_t lds = 2 * RG::LANES * sizeof(LdsPoint29);
+            const XYZZ<Fq> *rin = reinterpret_cast<const XYZZ<Fq> *>(red_in); XYZZ<Fq> *rout = reinterpret_cast<XYZZ<Fq> *>(gr.red_out.p);
+            if (red_l_log == RED_L_LOG_LARGE) hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_LARGE>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
+            else if (red_l_log == RED_L_LOG_SMALL) hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_SMALL>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
+            else hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_TINY>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
+        }
+    }
+    if (reduce29) {}
+    else if (red_l_log == RED_L_LOG_LARGE)
         hipLaunchKernelGGL((k_bucket_reduce<F, RED_L_LOG_LARGE>), dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), 2 * RG::LANES * sizeof(LdsPoint<F>), s,
                            red_in, g.B, gr.cpw, gr.red_out.as<XYZZ<F>>(), in_stride, L.red_out);
     else if (red_l_log == RED_L_LOG_SMALL)
@@ -1060,6 +1233,14 @@ static int window_table_build_t(WindowTable &t, const Affine<F> *d_bases, size_t
     return ZKG_OK;
 }
 int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s) { return window_table_build_t<Fq>(t, d_bases, n, c, s); }
+int window_table_records29(WindowTable &t, hipStream_t s) {
+    if (t.g2) { set_error("window_table_records29: G1 tables only"); return ZKG_ERROR; }
+    const size_t total = t.n * (size_t)t.W;
+    if (t.rec29.reserve(std::max<size_t>(1, total) * sizeof(Affine29))) return ZKG_ERROR;
+    if (total) hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t.buf.as<Affine<Fq>>(), total, t.rec29.as<Affine29>());
+    if (hipGetLastError() != hipSuccess) { set_error("window table records launch failed"); return ZKG_ERROR; }
+    return ZKG_OK;
+}
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s) { return window_table_build_t<Fq2>(t, d_bases, n, c, s); }
 
 // ---- witness split: classification and the flat sum of the bases whose scalar is one ----------------------------------

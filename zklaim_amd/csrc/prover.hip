@@ -442,7 +442,9 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = f
         if (ok) {
             DevBuf stage; const G1Affine *h_dev = (const G1Affine *)pk->H_query;
             if (!queries_on_device) { ok = upload(stage, pk->H_query, (m - 1) * 64) == 0; h_dev = stage.as<G1Affine>(); }
-            ok = ok && window_table_build_g1(crs->H_query, h_dev, m - 1, c_h, nullptr) == 0 && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+            static const bool h32 = getenv("ZKG_ACCUM_32") != nullptr;                          // (A/B switch: no 29-bit records)
+            ok = ok && window_table_build_g1(crs->H_query, h_dev, m - 1, c_h, nullptr) == 0 && (h32 || window_table_records29(crs->H_query, nullptr) == 0) &&
+                 hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
             stage.release();
         }
     }
@@ -569,7 +571,7 @@ static void lap(const ProverSlot &S, const char *what) {
     if (g_dbg_timing) fprintf(stderr, "[zkg] %-22s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
 }
 static MsmBases table_set(const WindowTable &t, bool g2, uint32_t index_sub, const uint32_t *remap = nullptr) {       // (a table not built yet is empty, not G1)
-    MsmBases b; b.p = t.buf.p; b.g2 = g2; b.level_stride = t.n; b.index_sub = index_sub; b.remap = remap; return b;
+    MsmBases b; b.p = t.buf.p; b.g2 = g2; b.level_stride = t.n; b.index_sub = index_sub; b.remap = remap; b.p29 = t.rec29.p; return b;
 }
 static MsmBases query_set(const DevBuf &q, bool g2, uint32_t index_sub) { MsmBases b; b.p = q.p; b.g2 = g2; b.index_sub = index_sub; return b; }
 

@@ -37,6 +37,10 @@ struct zkg_keypair {
     std::vector<G2Affine> B_g2;
     Fq12 alpha_beta;
     zkg_pk pk_view;
+    // the seam's generator (seam_keygen) leaves the five queries on the DEVICE instead (they become the resident key of the proofs that
+    // follow): the host vectors above stay empty, pk_view's query pointers are device pointers, b_idx lists the B query's non-zero entries
+    bool on_device = false; DevBuf dA, dB1, dB2, dH, dL; std::vector<uint32_t> b_idx;
+    ~zkg_keypair() { for (DevBuf *b : {&dA, &dB1, &dB2, &dH, &dL}) b->release(); }
 };
 
 namespace {
@@ -78,6 +82,17 @@ int batch_points(FN fixed_base_fn, const A &base, const std::vector<Fr> &scalars
     return rc;
 }
 
+// the same batch with its result left on the device
+template <class A, class FN>
+int batch_points_dev(FN fixed_base_fn, const A &base, const std::vector<Fr> &scalars, DevBuf &d_out) {
+    const size_t n = scalars.size();
+    if (d_out.reserve(n * sizeof(A) + 16)) return ZKG_ERROR;
+    if (!n) return ZKG_OK;
+    ScopedDevBuf d_s;
+    if (d_s.reserve(n * 32) || !hip_ok(hipMemcpy(d_s.p, scalars.data(), n * 32, hipMemcpyHostToDevice), "H2D", __FILE__, __LINE__)) return ZKG_ERROR;
+    return fixed_base_fn(base, d_s.as<uint32_t>(), n, d_out.as<A>(), nullptr, true);
+}
+
 G1Affine g1_generator() { return {Fq::from_u64(1), Fq::from_u64(2)}; }
 G2Affine g2_generator() {
     auto limbs = [](std::initializer_list<uint32_t> l) { Fq x; int i = 0; for (uint32_t v : l) x.v[i++] = v; return x; };
@@ -95,7 +110,11 @@ extern "C" {
 // The generator proper.  The constraint system comes either as the ABI's view (copied) or — `owned` — as CSR vectors the caller gives up
 // (the seam's circuit: 100 MB at 20 payloads that would otherwise be copied and then freed twice); `under_gpu` runs on a thread of its own
 // while the GPU turns the scalars into points (the seam destroys its circuit there).
-static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapdoor, OwnedCsr *owned, const std::function<void()> &under_gpu) {
+// keep_on_device: the seam's variant (seam_keygen below).  after_csr(kp) runs when the generator's host loops are done and its GPU phase
+// begins (kp holds the constraint system it will store) — the seam starts writing the pk blob's constraint rows there; before_delete()
+// runs before a failing generator deletes kp (whatever after_csr started must have let go of it).
+static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapdoor, OwnedCsr *owned, const std::function<void()> &under_gpu, bool keep_on_device = false,
+                                       const std::function<void(zkg_keypair *)> &after_csr = nullptr, const std::function<void()> &before_delete = nullptr) {
     if (!cs || (!owned && (!cs->a_rowptr || !cs->b_rowptr || !cs->c_rowptr))) { set_error("zkg_groth16_setup: null constraint system"); return nullptr; }
     zkg_keypair *kp = new zkg_keypair();
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
@@ -120,8 +139,9 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
         for (size_t i = 0; i <= n; ++i) { na += ta[i]; nb += tb[i]; }
         if (nb > na) { kp->rp[0].swap(kp->rp[1]); kp->col[0].swap(kp->col[1]); kp->val[0].swap(kp->val[1]); kp->swapped = true; }
     }
+    auto drop = [&]() -> zkg_keypair * { if (before_delete) before_delete(); delete kp; return nullptr; };
     DomainShape shape;                                                     // libfqfft get_evaluation_domain(C + l + 1)
-    if (!evaluation_domain_shape(C + l + 1, shape)) { set_error("zkg_groth16_setup: system too large for the 2-adicity of Fr"); delete kp; return nullptr; }
+    if (!evaluation_domain_shape(C + l + 1, shape)) { set_error("zkg_groth16_setup: system too large for the 2-adicity of Fr"); return drop(); }
     const unsigned log_m = shape.log_m;
     kp->log_m = log_m; kp->m = shape.m;
     const size_t m = shape.m;
@@ -131,7 +151,7 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
     lap("copy + swap");
     // ---- Lagrange coefficients u_i = L_i(t) and Z(t) on the chosen domain (closed forms, one batched inversion)
     Fr Zt; std::vector<Fr> u;
-    if (domain_lagrange(shape, t, u, Zt)) { delete kp; return nullptr; }
+    if (domain_lagrange(shape, t, u, Zt)) return drop();
     lap("lagrange");
     // ---- QAP polynomials at t (r1cs_to_qap_instance_map_with_evaluation)
     std::vector<Fr> At(n + 1, Fr::zero()), Bt(n + 1, Fr::zero()), Ct(n + 1, Fr::zero());
@@ -164,7 +184,10 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
         }
     });
     lap("qap evaluation + scalars");
-    // ---- scalars -> points (GPU fixed-base batches)
+    // ---- scalars -> points (GPU fixed-base batches).  The host pool is free from here on: what after_csr starts (the seam: the pk blob's
+    //      constraint rows) shares it with nothing but the short page pre-faulting below (started earlier it made the Lagrange and QAP
+    //      loops above run inline on this thread: 37 -> 90 ms)
+    if (after_csr) after_csr(kp);
     std::thread side;
     if (under_gpu) side = std::thread([&] { try { under_gpu(); } catch (...) {} });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_side{side};
@@ -172,6 +195,17 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
     std::vector<G1Affine> small1; std::vector<G2Affine> small2;
     // the result vectors (250 MB at 20 payloads) get their pages on the pool, side by side, instead of one after the other inside the batches
     static const bool no_prefault = getenv("ZKG_NO_PREFAULT") != nullptr;
+    if (keep_on_device) {
+        // the seam: ~4n + m points computed into device buffers and left there; only the 8 key elements and the l + 1 points of the
+        // verification key come back
+        kp->on_device = true;
+        for (size_t i = 0; i < Bt.size(); ++i) if (!Bt[i].is_zero()) kp->b_idx.push_back((uint32_t)i);       // zero scalar <=> point at infinity
+        const bool okd = batch_points<G1Affine>(fixed_base_g1, g1, {alpha, beta, delta}, small1) == 0 && batch_points<G2Affine>(fixed_base_g2, g2, {beta, delta, gamma}, small2) == 0 &&
+                         batch_points_dev<G1Affine>(fixed_base_g1, g1, At, kp->dA) == 0 && batch_points_dev<G1Affine>(fixed_base_g1, g1, Bt, kp->dB1) == 0 &&
+                         batch_points_dev<G2Affine>(fixed_base_g2, g2, Bt, kp->dB2) == 0 && batch_points_dev<G1Affine>(fixed_base_g1, g1, Hs, kp->dH) == 0 &&
+                         batch_points_dev<G1Affine>(fixed_base_g1, g1, Ls, kp->dL) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, ICs, kp->IC) == 0;
+        if (!okd) return drop();
+    } else {
     if (!no_prefault) host_parallel_for(5, [&](int i) {
         if (i == 0) kp->B_g2.resize(Bt.size()); else if (i == 1) kp->A_query.resize(At.size()); else if (i == 2) kp->B_g1.resize(Bt.size());
         else if (i == 3) kp->H_query.resize(Hs.size()); else kp->L_query.resize(Ls.size());
@@ -180,7 +214,8 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
               batch_points<G1Affine>(fixed_base_g1, g1, At, kp->A_query) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Bt, kp->B_g1) == 0 &&
               batch_points<G2Affine>(fixed_base_g2, g2, Bt, kp->B_g2) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, Hs, kp->H_query) == 0 &&
               batch_points<G1Affine>(fixed_base_g1, g1, Ls, kp->L_query) == 0 && batch_points<G1Affine>(fixed_base_g1, g1, ICs, kp->IC) == 0;
-    if (!ok) { delete kp; return nullptr; }
+    if (!ok) return drop();
+    }
     kp->alpha_g1 = small1[0]; kp->beta_g1 = small1[1]; kp->delta_g1 = small1[2];
     kp->beta_g2 = small2[0]; kp->delta_g2 = small2[1]; kp->gamma_g2 = small2[2];
     lap("fixed-base batches (GPU)");
@@ -196,6 +231,9 @@ static zkg_keypair *groth16_setup_impl(const zkg_r1cs *cs, const uint64_t *trapd
     v.beta_g2 = (const uint64_t *)&kp->beta_g2; v.delta_g2 = (const uint64_t *)&kp->delta_g2;
     v.A_query = (const uint64_t *)kp->A_query.data(); v.B_g1 = (const uint64_t *)kp->B_g1.data(); v.B_g2 = (const uint64_t *)kp->B_g2.data();
     v.H_query = (const uint64_t *)kp->H_query.data(); v.L_query = (const uint64_t *)kp->L_query.data();
+    if (kp->on_device) {                                                         // DEVICE pointers: for crs_upload_device_queries only
+        v.A_query = kp->dA.as<uint64_t>(); v.B_g1 = kp->dB1.as<uint64_t>(); v.B_g2 = kp->dB2.as<uint64_t>(); v.H_query = kp->dH.as<uint64_t>(); v.L_query = kp->dL.as<uint64_t>();
+    }
     return kp;
 }
 zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5 x 4 canonical limbs: t, alpha, beta, gamma, delta; NULL = random */) {
@@ -203,11 +241,29 @@ zkg_keypair *zkg_groth16_setup(const zkg_r1cs *cs, const uint64_t *trapdoor /* 5
 }
 
 void zkg_keypair_free(zkg_keypair *kp) { delete kp; }
-const zkg_pk *zkg_keypair_pk(const zkg_keypair *kp) { return kp ? &kp->pk_view : nullptr; }
+const zkg_pk *zkg_keypair_pk(const zkg_keypair *kp) { return kp && !kp->on_device ? &kp->pk_view : nullptr; }
 int zkg_keypair_swapped(const zkg_keypair *kp) { return kp && kp->swapped ? 1 : 0; }
 
 // operator<<(r1cs_gg_ppzksnark_proving_key), layout in codec.hip.  Built once per keypair (callers ask for the size first, then for
 // the bytes); the fixed-size point records — 2.2 M of them at 20 payloads — are serialised on the host pool.
+// the constraint rows of a pk blob (per row: a, b, c as #terms '\n' (index '\n' coefficient)*), in chunks written on the host pool
+static void constraint_rows_text(const zkg_keypair *kp, std::vector<ser::Writer> &part) {
+    const int chunks = (int)std::min<size_t>(64, ((size_t)kp->C + 4095) / 4096);
+    part.assign(std::max(chunks, 1), ser::Writer());
+    auto rows = [&](int ch) {
+        ser::Writer &pw = part[ch];
+        const uint32_t lo = (uint32_t)((size_t)kp->C * ch / std::max(chunks, 1)), hi = (uint32_t)((size_t)kp->C * (ch + 1) / std::max(chunks, 1));
+        size_t terms = 0;
+        for (int k = 0; k < 3; ++k) terms += kp->rp[k][hi] - kp->rp[k][lo];
+        pw.buf.reserve(terms * 40 + (size_t)(hi - lo) * 8 + 64);
+        for (uint32_t c = lo; c < hi; ++c)
+            for (int k = 0; k < 3; ++k) {
+                pw.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
+                for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { pw.dec(kp->col[k][e]); pw.raw(&kp->val[k][4 * (size_t)e], 32); }
+            }
+    };
+    if (chunks <= 1) rows(0); else host_parallel_for(chunks, rows);
+}
 static void build_pk_blob(const zkg_keypair *kp, ser::Bytes &buf) {
     ser::Writer w;
     std::vector<size_t> idx;
@@ -234,21 +290,8 @@ static void build_pk_blob(const zkg_keypair *kp, ser::Bytes &buf) {
     w.dec(kp->l); w.dec(kp->n - kp->l); w.dec(kp->C);
     {   // the constraint system: variable-length records (decimal counts and indices), so each chunk of rows is written to a buffer of its
         // own on the pool and the buffers are then copied into place, also in parallel
-        const int chunks = (int)std::min<size_t>(64, ((size_t)kp->C + 4095) / 4096);
-        std::vector<ser::Writer> part(std::max(chunks, 1));
-        auto rows = [&](int ch) {
-            ser::Writer &pw = part[ch];
-            const uint32_t lo = (uint32_t)((size_t)kp->C * ch / std::max(chunks, 1)), hi = (uint32_t)((size_t)kp->C * (ch + 1) / std::max(chunks, 1));
-            size_t terms = 0;
-            for (int k = 0; k < 3; ++k) terms += kp->rp[k][hi] - kp->rp[k][lo];
-            pw.buf.reserve(terms * 40 + (size_t)(hi - lo) * 8 + 64);
-            for (uint32_t c = lo; c < hi; ++c)
-                for (int k = 0; k < 3; ++k) {
-                    pw.dec(kp->rp[k][c + 1] - kp->rp[k][c]);
-                    for (uint32_t e = kp->rp[k][c]; e < kp->rp[k][c + 1]; ++e) { pw.dec(kp->col[k][e]); pw.raw(&kp->val[k][4 * (size_t)e], 32); }
-                }
-        };
-        if (chunks <= 1) rows(0); else host_parallel_for(chunks, rows);
+        std::vector<ser::Writer> part;
+        constraint_rows_text(kp, part);
         std::vector<size_t> at(part.size() + 1, w.buf.size());
         for (size_t i = 0; i < part.size(); ++i) at[i + 1] = at[i] + part[i].buf.size();
         w.buf.resize(at.back());
@@ -258,7 +301,7 @@ static void build_pk_blob(const zkg_keypair *kp, ser::Bytes &buf) {
 }
 size_t zkg_keypair_pk_blob(const zkg_keypair *kp_, uint8_t *out, size_t cap) {
     zkg_keypair *kp = const_cast<zkg_keypair *>(kp_);
-    if (!kp) return 0;
+    if (!kp || kp->on_device) return 0;
     std::lock_guard<std::mutex> lk(kp->blob_mu);
     if (kp->pk_blob.empty()) build_pk_blob(kp, kp->pk_blob);
     if (out && cap >= kp->pk_blob.size()) {                                   // hundreds of MB into fresh pages: copy in parallel pieces
@@ -432,4 +475,120 @@ int zkg_pairing_selfcheck(const uint32_t *e, int nlimbs) {
 // the seam's entry (compat.hip): sizes in `cs`, the CSR arrays given up in `owned`
 zkg_keypair *groth16_setup_owned(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu) {
     return groth16_setup_impl(cs, nullptr, owned, under_gpu);
+}
+
+zkg_crs *crs_upload_device_queries(const zkg_pk *pk, const std::function<bool()> &constraint_system_ready);   // prover.hip
+
+// a finished generator's keypair is destroyed on a thread of its own (one at a time: the next one, and seam_keygen_quiesce, wait for it)
+// (the thread object lives on the heap and is never destroyed: a C caller that exits without zkg_shutdown must not meet the destructor of
+//  a joinable std::thread; an atexit handler joins it before the runtime goes away)
+static std::mutex &discard_mu() { static std::mutex *m = new std::mutex(); return *m; }
+static std::thread &discard_thread() { static std::thread *t = new std::thread(); return *t; }
+void seam_keygen_quiesce() {
+    std::lock_guard<std::mutex> lk(discard_mu());
+    if (discard_thread().joinable()) discard_thread().join();
+}
+static void keypair_discard(zkg_keypair *kp, int device) {
+    static const bool registered = [] { return std::atexit(seam_keygen_quiesce) == 0; }();
+    (void)registered;
+    std::lock_guard<std::mutex> lk(discard_mu());
+    if (discard_thread().joinable()) discard_thread().join();
+    discard_thread() = std::thread([kp, device] { (void)hipSetDevice(device); delete kp; });
+}
+
+// libsnark_trusted_setup's generator (zklaim/libsnark_wrapper.cpp:195-215) as the seam runs it.  The reference's protocol is setup -> ONE
+// prove -> verify per key (src/main_benchmark.c:113-148), so the key this call generates is the key the next libsnark_prove needs:
+// the ~4n + m query points are computed into device buffers and stay there as the resident key (zkg_crs, H table included); the pk blob
+// the C caller receives is assembled from GPU-compressed records (34 / 100 bytes per point instead of 64 / 192 over PCIe, no host point
+// vectors at all) around the constraint rows' text, which the host pool writes meanwhile.  Same bytes as zkg_keypair_pk_blob writes.
+// pk / vk: malloc'd (the caller's to free).  on_blob runs on a thread of its own as soon as the pk blob is complete (the seam hashes it).
+int seam_keygen(const zkg_r1cs *cs, zk::OwnedCsr *owned, const std::function<void()> &under_gpu, unsigned char **pk_out, size_t *pk_len,
+                unsigned char **vk_out, size_t *vk_len, zkg_crs **crs_out, const std::function<void(const unsigned char *, size_t)> &on_blob) {
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[zkg seam keygen] %-26s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
+    *pk_out = *vk_out = nullptr; *crs_out = nullptr;
+    // ---- the constraint rows' text starts as soon as the generator has fixed the system it stores (a thread of its own that fans out over
+    //      the host pool): it is the longest host-only part of the blob and needs nothing the GPU computes
+    int device = 0; (void)hipGetDevice(&device);                               // threads started below bind to the caller's device
+    std::unique_ptr<zkg_keypair> kp;                                            // (declared first: outlives every thread that reads it)
+    std::vector<ser::Writer> rows_part; bool rows_ok = true;
+    std::thread rows_thread;
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_rows{rows_thread};
+    kp.reset(groth16_setup_impl(cs, nullptr, owned, under_gpu, true,
+        [&](zkg_keypair *k) { rows_thread = std::thread([&rows_part, &rows_ok, k] { try { constraint_rows_text(k, rows_part); } catch (...) { rows_ok = false; } }); },
+        [&] { if (rows_thread.joinable()) rows_thread.join(); }));
+    if (!kp) return ZKG_ERROR;
+    lap("points on the device");
+    // ---- the resident key is built from the device queries on a thread of its own (null stream: H table, constraint system upload, comb
+    //      tables, domain, prover slot) while this thread turns the same queries into the blob's records on a stream of its own
+    zkg_crs *crs = nullptr;
+    std::thread crs_thread([&] { try { (void)hipSetDevice(device); crs = crs_upload_device_queries(&kp->pk_view, nullptr); } catch (...) { crs = nullptr; } });
+    struct JoinCrs { std::thread &t; zkg_crs *&c; bool keep = false; ~JoinCrs() { if (t.joinable()) t.join(); if (!keep && c) { zkg_crs_free(c); c = nullptr; } } } join_crs{crs_thread, crs};
+    // ---- layout: everything before the constraint rows has a known size
+    const size_t nA = (size_t)kp->n + 1, nidx = kp->b_idx.size(), nH = kp->m - 1, nL = (size_t)kp->n - kp->l;
+    ser::Writer seg[5];
+    seg[0].g1(kp->alpha_g1); seg[0].g1(kp->beta_g1); seg[0].g2(kp->beta_g2); seg[0].g1(kp->delta_g1); seg[0].g2(kp->delta_g2); seg[0].dec(nA);
+    seg[1].buf.reserve(nidx * 8 + 64);
+    seg[1].dec(nA); seg[1].dec(nidx); for (uint32_t i : kp->b_idx) seg[1].dec(i); seg[1].dec(nidx);
+    seg[2].dec(nH); seg[3].dec(nL); seg[4].dec(kp->l); seg[4].dec(kp->n - kp->l); seg[4].dec(kp->C);
+    const size_t run[4] = {nA * 34, nidx * 100, nH * 34, nL * 34};
+    size_t at_seg[5], at_run[4], pos = 0;
+    for (int i = 0; i < 5; ++i) { at_seg[i] = pos; pos += seg[i].buf.size(); if (i < 4) { at_run[i] = pos; pos += run[i]; } }
+    const size_t rows_at = pos;
+    size_t terms = 0; for (int k = 0; k < 3; ++k) terms += kp->col[k].size();
+    const size_t rows_bound = terms * 44 + (size_t)kp->C * 3 * 12 + 64;        // an index is at most 10 digits + '\n', a count likewise
+    unsigned char *pk = (unsigned char *)malloc(rows_at + rows_bound);          // (untouched pages of the bound cost nothing; shrunk below)
+    if (!pk) { set_error("seam_keygen: out of memory"); return ZKG_ERROR; }
+    struct FreeOnExit { unsigned char *&p; ~FreeOnExit() { free(p); } } free_pk{pk};
+    for (int i = 0; i < 5; ++i) memcpy(pk + at_seg[i], seg[i].buf.data(), seg[i].buf.size());
+    // ---- the GPU compresses the points into the blob's records; they come back, run by run, straight into the blob
+    {
+        ScopedDevBuf d_rec, d_idx;
+        hipStream_t st = nullptr;
+        if (!hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__)) return ZKG_ERROR;
+        struct DropStream { hipStream_t s; ~DropStream() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } drop_stream{st};
+        size_t off[4], total = 0;
+        for (int i = 0; i < 4; ++i) { off[i] = total; total += (run[i] + 15) & ~(size_t)15; }
+        if (d_rec.reserve(total + 16) || d_idx.reserve(nidx * 4 + 16) ||
+            (nidx && !hip_ok(hipMemcpyAsync(d_idx.p, kp->b_idx.data(), nidx * 4, hipMemcpyHostToDevice, st), "H2D", __FILE__, __LINE__))) return ZKG_ERROR;
+        uint8_t *r = d_rec.as<uint8_t>();
+        if (compress_g1_records(kp->dA.as<G1Affine>(), nA, r + off[0], st) || compress_kc_records(kp->dB2.as<G2Affine>(), kp->dB1.as<G1Affine>(), d_idx.as<uint32_t>(), nidx, r + off[1], st) ||
+            compress_g1_records(kp->dH.as<G1Affine>(), nH, r + off[2], st) || compress_g1_records(kp->dL.as<G1Affine>(), nL, r + off[3], st)) { set_error("seam_keygen: compression launch failed"); return ZKG_ERROR; }
+        for (int i = 0; i < 4; ++i)
+            if (run[i] && !hip_ok(hipMemcpyAsync(pk + at_run[i], r + off[i], run[i], hipMemcpyDeviceToHost, st), "D2H", __FILE__, __LINE__)) return ZKG_ERROR;
+        if (!hip_ok(hipStreamSynchronize(st), "sync", __FILE__, __LINE__)) return ZKG_ERROR;
+    }
+    lap("records compressed + copied");
+    rows_thread.join();
+    size_t rows_len = 0;
+    if (rows_ok) {
+        std::vector<size_t> at(rows_part.size() + 1, rows_at);
+        for (size_t i = 0; i < rows_part.size(); ++i) at[i + 1] = at[i] + rows_part[i].buf.size();
+        rows_len = at.back() - rows_at;
+        if (rows_len > rows_bound) rows_ok = false;
+        else host_parallel_for((int)rows_part.size(), [&](int i) { if (!rows_part[i].buf.empty()) memcpy(pk + at[i], rows_part[i].buf.data(), rows_part[i].buf.size()); });
+    }
+    if (!rows_ok) { set_error("seam_keygen: constraint rows failed"); return ZKG_ERROR; }
+    const size_t len = rows_at + rows_len;
+    { unsigned char *shrunk = (unsigned char *)realloc(pk, len); if (shrunk) pk = shrunk; }
+    lap("pk blob complete");
+    std::thread blob_thread;
+    if (on_blob) blob_thread = std::thread([&] { try { on_blob(pk, len); } catch (...) {} });
+    struct Join2 { std::thread &t; ~Join2() { if (t.joinable()) t.join(); } } join_blob{blob_thread};
+    // ---- vk (l + 1 points, host)
+    const size_t vlen = zkg_keypair_vk_blob(kp.get(), nullptr, 0);
+    unsigned char *vk = (unsigned char *)malloc(vlen);
+    if (!vk || zkg_keypair_vk_blob(kp.get(), vk, vlen) != vlen) { free(vk); set_error("seam_keygen: vk blob failed"); return ZKG_ERROR; }
+    crs_thread.join();
+    lap("resident key built");
+    if (!crs) { free(vk); return ZKG_ERROR; }
+    if (blob_thread.joinable()) blob_thread.join();
+    join_crs.keep = true;
+    // the keypair's host vectors (the constraint system, 100 MB at 20 payloads) and device queries go back to their allocators on a thread
+    // of their own: nothing below needs them
+    keypair_discard(kp.release(), device);
+    *pk_out = pk; *pk_len = len; *vk_out = vk; *vk_len = vlen; *crs_out = crs;
+    pk = nullptr;                                                               // handed over
+    return ZKG_OK;
 }
