@@ -145,6 +145,13 @@ def main():
             l29.append(f'    "{t}\\n\\t" \\')
         l29.append('    ""')
         l29.append("")
+    ins = gen_f29(False, modulus=F29_R)
+    l29.append(f"// Fr MUL: {len(ins)} instructions, {sum(1 for t in ins if t.startswith('v_mad'))} v_mad_u64_u32")
+    l29.append("#define ZK_F29R_MUL_ASM \\")
+    for t in ins:
+        l29.append(f'    "{t}\\n\\t" \\')
+    l29.append('    ""')
+    l29.append("")
     l29.append("#define ZK_F29_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
     l29.append("#define ZK_F29_CLOBBERS2 " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"v{i}"' for i in range(14, 25)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
     open(dst29, "w").write("\n".join(l29) + "\n")
@@ -253,9 +260,12 @@ def selftest_addsub():
 F29_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
 
-def gen_f29(square, col=2, m0=4, out0=0, a0=9, b0=18, consts=True):
+F29_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617      # Fr: the NTT's butterflies (csrc/ntt.hip)
+
+
+def gen_f29(square, col=2, m0=4, out0=0, a0=9, b0=18, consts=True, modulus=None):
     """one product: column accumulator v[col:col+1], quotient digits v{m0}.., operands %{out0}.. result, %{a0}.. a, %{b0}.. b"""
-    q = F29_P
+    q = modulus or F29_P
     P = [(q >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
     inv = (-pow(q, -1, 1 << 29)) % (1 << 29)
     A = lambda i: f"%{a0 + i}"
@@ -370,6 +380,12 @@ def selftest_f29():
     value = lambda l: sum(x << (29 * i) for i, x in enumerate(l))
     ops = lambda base, l: {base + i: x for i, x in enumerate(l)}
     mul, sqr, mul2, sqr2 = gen_f29(False), gen_f29(True), gen_f29_dual(False), gen_f29_dual(True)
+    mul_r = gen_f29(False, modulus=F29_R)
+    rinv_r = pow(1 << 261, -1, F29_R)
+    for t in range(200):                                                         # Fr: values as the NTT's butterflies feed them (one side below r, the other below 60 r)
+        a = rnd.randrange(60 * F29_R); b = rnd.randrange(F29_R)
+        got = value(simulate_f29(mul_r, {**ops(9, limbs(a)), **ops(18, limbs(b))}))
+        assert got < 2 * F29_R and got % F29_R == a * b * rinv_r % F29_R, ("mul Fr", t)
     for t in range(300):
         a = rnd.randrange(13 * q) if t > 3 else [0, 1, q - 1, 13 * q - 1][t]
         b = rnd.randrange(13 * q) if t > 3 else [0, q - 1, q - 1, 13 * q - 1][t]

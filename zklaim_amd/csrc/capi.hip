@@ -296,7 +296,7 @@ int zkg_ntt_domain_dev(void *d_a, size_t m, int inverse, int coset, void *stream
     StepDomain *d = step_domain(m, s);
     if (!d) return ZKG_ERROR;
     DevBuf scratch;                                           // one-off call: the prover keeps its own
-    if (scratch.reserve(m * 32)) return ZKG_ERROR;
+    if (scratch.reserve(m * NTT_SCRATCH_BYTES)) return ZKG_ERROR;
     int rc = step_ntt_run(d, (Fr *)d_a, inverse != 0, coset != 0, s, scratch.as<Fr>());
     if (!hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__)) rc = ZKG_ERROR;
     scratch.release();

@@ -55,7 +55,8 @@ struct NttDomain {
     DevBuf tw_fwd, tw_inv;        // omega^i, omega^-i, i < N/2
     DevBuf coset_pre;             // g^i               (cosetFFT pre-multiplication)
     DevBuf icoset_post;           // g^-i / N          (icosetFFT post-multiplication, 1/N folded in)
-    DevBuf scratch;               // N elements
+    DevBuf tw_fwd29, tw_inv29, coset_pre29, icoset_post29;   // the same tables as 40-byte 29-bit records (fr29.hip.hpp), read by k_ntt_pass29
+    DevBuf scratch;               // N elements (40-byte records: the 29-bit passes' form between passes)
     Fr n_inv;                     // 1/N
     std::mutex mu; bool first_stream_set = false; hipStream_t first_stream = nullptr;
     std::map<hipStream_t, DevBuf> stream_scratch;
@@ -69,8 +70,12 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s);     // cached per size
 int ntt_run(NttDomain *d, Fr *d_a, int inverse, int coset, hipStream_t s);
 // batch > 1: `batch` vectors, batch_stride elements apart (0 = N: back to back) in d_a and in `scratch` (which must then be given),
 // one launch per pass
+// pre29 / post29: the 29-bit twins of a caller's own pre / post table (ntt_table29); without them such a call takes the 32-bit pass.
+// A caller's scratch holds 40 bytes per element (NTT_SCRATCH_BYTES).
+static constexpr size_t NTT_SCRATCH_BYTES = 40;
 int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch = nullptr,
-               unsigned batch = 1, size_t batch_stride = 0);
+               unsigned batch = 1, size_t batch_stride = 0, const void *pre29 = nullptr, const void *post29 = nullptr);
+int ntt_table29(DevBuf &out, const Fr *d_in, size_t n, hipStream_t s);       // a table in libff's form -> its 29-bit records
 
 // libfqfft get_evaluation_domain(min_size) for min_size <= 2^28: basic_radix2_domain (m = 2^k) or step_radix2_domain (m = big + small,
 // big = 2^(ceil_log2(m)-1), small = 2^b < big).  zklaim's circuits land on a step domain for 10 of the 20 payload counts.

@@ -12,6 +12,7 @@
 // per-domain table omega^i (i < N/2) that stays L2/MALL resident.
 // MFMA is not used: the work is 254-bit modular multiplication on the integer VALU.
 #include "common.hpp"
+#include "fr29.hip.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
 #include <cstdlib>
@@ -87,6 +88,83 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs A) {
     }
 }
 
+// ---- the same pass on the 29-bit representation (fr29.hip.hpp): 40-byte records in LDS and between passes, libff's form at the
+//      transform's two ends only.  Tables (twiddles, pre / post scalings) are 29-bit records made once per domain (k_table29).
+struct NttPassArgs29 {
+    const void *src; void *dst; const Rec29 *tw, *pre, *post;
+    uint32_t post_scalar[9];
+    uint32_t n_log, s0, R, cw_log, first, last, has_post_scalar, row_pad;      // row_pad: records of padding per LDS row
+    size_t src_batch_stride, dst_batch_stride;      // elements between the vectors of a batch (blockIdx.y), in the units of src / dst
+};
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
+    extern __shared__ U4 smem[];
+    Rec29 *lds = reinterpret_cast<Rec29 *>(smem);
+    const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = CW + A.row_pad;
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, nthr = blockDim.x;
+    const uint32_t s1 = A.s0 + A.R;
+    const uint32_t lo_mask = (1u << A.s0) - 1;
+    const Fr *src_abi = reinterpret_cast<const Fr *>(A.src) + (size_t)blockIdx.y * A.src_batch_stride;
+    const Rec29 *src_rec = reinterpret_cast<const Rec29 *>(A.src) + (size_t)blockIdx.y * A.src_batch_stride;
+    Fr *dst_abi = reinterpret_cast<Fr *>(A.dst) + (size_t)blockIdx.y * A.dst_batch_stride;
+    Rec29 *dst_rec = reinterpret_cast<Rec29 *>(A.dst) + (size_t)blockIdx.y * A.dst_batch_stride;
+
+    // ---- load tile
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {
+        uint32_t c = e & (CW - 1), mid = e >> A.cw_log;
+        size_t idx; uint32_t row;
+        if (A.first) { idx = (size_t)mid * ((size_t)1 << (A.n_log - A.R)) + (size_t)tile * CW + c; row = bitrev(mid, A.R); }
+        else { uint32_t g = tile * CW + c; idx = ((size_t)(g >> A.s0) << s1) + ((size_t)mid << A.s0) + (g & lo_mask); row = mid; }
+        Fr29 v = A.first ? fr29::slice(src_abi[idx]) : fr29::load_rec(src_rec + idx);
+        if (A.pre) v = fr29::mul(v, fr29::load_rec(A.pre + idx));
+        fr29::store_rec(lds + row * stride + c, v);
+    }
+    __syncthreads();
+
+    // ---- R butterfly stages in LDS
+    for (uint32_t q = 0; q < A.R; ++q) {
+        const uint32_t s = A.s0 + q, half = 1u << q;
+        for (uint32_t bf = tid; bf < (rows >> 1) * CW; bf += nthr) {
+            uint32_t c = bf & (CW - 1), k = bf >> A.cw_log;
+            uint32_t j = k & (half - 1), r0 = ((k >> q) << (q + 1)) | j, r1 = r0 + half;
+            const Fr29 u = fr29::load_rec(lds + r0 * stride + c);
+            Fr29 v = fr29::load_rec(lds + r1 * stride + c);
+            if (s != 0) {
+                uint32_t lo = A.first ? 0u : ((tile * CW + c) & lo_mask);
+                size_t e = ((size_t)((j << A.s0) + lo)) << (A.n_log - 1 - s);
+                v = fr29::mul(v, fr29::load_rec(A.tw + e));
+            }
+            fr29::store_rec(lds + r0 * stride + c, fr29::add_norm(u, v));
+            fr29::store_rec(lds + r1 * stride + c, fr29::sub_norm(u, v));
+        }
+        __syncthreads();
+    }
+
+    // ---- store tile
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {
+        uint32_t c, mid; size_t idx;
+        if (A.first) { mid = e & (rows - 1); c = e >> A.R; idx = ((size_t)bitrev(tile * CW + c, A.n_log - A.R) << A.R) + mid; }
+        else { c = e & (CW - 1); mid = e >> A.cw_log; uint32_t g = tile * CW + c; idx = ((size_t)(g >> A.s0) << s1) + ((size_t)mid << A.s0) + (g & lo_mask); }
+        Fr29 v = fr29::load_rec(lds + mid * stride + c);
+        if (!A.last) { fr29::store_rec(dst_rec + idx, v); continue; }
+        Fr29 f;                                                      // the last product: post table, 1/N, or one — below 2r either way
+        if (A.post) f = fr29::load_rec(A.post + idx);
+        else if (A.has_post_scalar) { for (int i = 0; i < 9; ++i) f.v[i] = A.post_scalar[i]; }
+        else { for (int i = 0; i < 9; ++i) f.v[i] = fr29::ONE[i]; }
+        dst_abi[idx] = fr29::unslice_reduce(fr29::mul(v, f));
+    }
+}
+// a table of Fr elements in libff's form -> 29-bit records of x R' (x 2^256 times 32 = x 2^261, sliced)
+__global__ __launch_bounds__(256) void k_table29(const Fr *in, size_t n, Fr c32, Rec29 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr29::store_rec(out + i, fr29::slice((in[i] * c32).normalized()));
+}
+int ntt_table29(DevBuf &out, const Fr *d_in, size_t n, hipStream_t s) {
+    if (out.reserve(std::max<size_t>(1, n) * sizeof(Rec29))) return ZKG_ERROR;
+    if (n) hipLaunchKernelGGL(k_table29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, n, Fr::from_u64(32), out.as<Rec29>());
+    return hipGetLastError() == hipSuccess ? ZKG_OK : ZKG_ERROR;
+}
+
 // out[i] = scale * base^i : each thread seeds base^(64 t) by square-and-multiply, then walks 64 entries
 __global__ void k_powers(Fr *out, size_t n, Fr base, Fr scale) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,15 +201,18 @@ int NttDomain::init(unsigned logn_, hipStream_t s) {
     n_inv = Fr::from_u64(N).inverse();
     size_t half = N > 1 ? N / 2 : 1;
     if (tw_fwd.reserve(half * sizeof(Fr)) || tw_inv.reserve(half * sizeof(Fr)) || coset_pre.reserve(N * sizeof(Fr)) ||
-        icoset_post.reserve(N * sizeof(Fr)) || scratch.reserve(N * sizeof(Fr))) return ZKG_ERROR;
+        icoset_post.reserve(N * sizeof(Fr)) || scratch.reserve(N * sizeof(Rec29))) return ZKG_ERROR;
     if (powers_table(tw_fwd.as<Fr>(), half, omega, Fr::one(), s)) return ZKG_ERROR;
     if (powers_table(tw_inv.as<Fr>(), half, omega.inverse(), Fr::one(), s)) return ZKG_ERROR;
     if (powers_table(coset_pre.as<Fr>(), N, g, Fr::one(), s)) return ZKG_ERROR;
     if (powers_table(icoset_post.as<Fr>(), N, g.inverse(), n_inv, s)) return ZKG_ERROR;
+    if (ntt_table29(tw_fwd29, tw_fwd.as<Fr>(), half, s) || ntt_table29(tw_inv29, tw_inv.as<Fr>(), half, s) ||
+        ntt_table29(coset_pre29, coset_pre.as<Fr>(), N, s) || ntt_table29(icoset_post29, icoset_post.as<Fr>(), N, s)) return ZKG_ERROR;
     return ZKG_OK;
 }
 void NttDomain::release() {
     tw_fwd.release(); tw_inv.release(); coset_pre.release(); icoset_post.release(); scratch.release();
+    tw_fwd29.release(); tw_inv29.release(); coset_pre29.release(); icoset_post29.release();
     for (auto &kv : stream_scratch) kv.second.release();
     stream_scratch.clear();
 }
@@ -141,7 +222,7 @@ Fr *NttDomain::scratch_for(hipStream_t s) {
     if (first_stream_set && s == first_stream) return scratch.as<Fr>();
     if (!first_stream_set) { first_stream_set = true; first_stream = s; return scratch.as<Fr>(); }
     DevBuf &b = stream_scratch[s];
-    if (b.reserve(((size_t)1 << logn) * sizeof(Fr))) return nullptr;
+    if (b.reserve(((size_t)1 << logn) * sizeof(Rec29))) return nullptr;
     return b.as<Fr>();
 }
 
@@ -158,7 +239,8 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s) {
     return d;
 }
 int ntt_configure() {
-    return hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? ZKG_OK : ZKG_ERROR;
+    return hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void *)k_ntt_pass29, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
 void ntt_release_all() {
     std::lock_guard<std::mutex> lk(g_dom_mu);
@@ -168,11 +250,17 @@ void ntt_release_all() {
     g_step_domains.clear();
 }
 
-int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch, unsigned batch, size_t batch_stride) {
+int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *post, const Fr *post_scalar, hipStream_t s, Fr *scratch, unsigned batch, size_t batch_stride,
+               const void *pre29, const void *post29) {
     const unsigned n = d->logn;
     if (n == 0) return ZKG_OK;                 // N = 1: every variant is the identity (g^0 = 1, 1/N = 1)
     if (batch > 1 && !scratch) { set_error("ntt: a batched transform needs its own scratch"); return ZKG_ERROR; }
     const size_t N = (size_t)1 << n;
+    // the domain's own scaling tables have 29-bit twins; a caller's table needs its twin passed along (ntt_table29), else the 32-bit pass runs
+    if (pre && !pre29 && pre == d->coset_pre.as<Fr>()) pre29 = d->coset_pre29.p;
+    if (post && !post29 && post == d->icoset_post.as<Fr>()) post29 = d->icoset_post29.p;
+    static const bool ntt32 = getenv("ZKG_NTT_32") != nullptr;                                          // A/B switch
+    const bool use29 = !ntt32 && (!pre || pre29) && (!post || post29);
     // elements per workgroup tile, measured (MI355X): 512 up to 2^20 (2^18: 0.057 ms against 0.099 ms with 2048-element tiles:
     // four times as many workgroups and 4+ of them per CU, so one tile's loads run under another's butterflies), 1024 above;
     // one thread per butterfly of a stage
@@ -203,6 +291,26 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
         size_t rows = (size_t)1 << R, CW = (size_t)1 << A.cw_log;
         size_t lds = rows * (2 * CW + 1) * 16;
         unsigned threads = (unsigned)std::min<size_t>(NTT_THREADS, std::max<size_t>(64, rows * CW / 2));
+        if (use29) {
+            NttPassArgs29 B;
+            B.first = A.first; B.last = (p == npass - 1);
+            B.src = A.src; B.dst = A.dst;                                                     // (tmp holds 40-byte records on this path)
+            B.tw = (inverse ? d->tw_inv29 : d->tw_fwd29).as<Rec29>();
+            B.pre = (p == 0) ? reinterpret_cast<const Rec29 *>(pre29) : nullptr;
+            B.post = B.last ? reinterpret_cast<const Rec29 *>(post29) : nullptr;
+            B.has_post_scalar = A.has_post_scalar;
+            if (B.has_post_scalar) {                                                          // x 2^256 -> x 2^261, sliced (host)
+                const Fr c = (*post_scalar * Fr::from_u64(32));
+                for (int i = 0; i < 9; ++i) { const int bit = 29 * i, l = bit >> 5, sh = bit & 31; uint64_t w = c.v[l]; if (l + 1 < 8) w |= (uint64_t)c.v[l + 1] << 32; B.post_scalar[i] = (uint32_t)(w >> sh) & (i < 8 ? Fr29::M : 0xffffffffu); }
+            }
+            B.n_log = n; B.s0 = s0; B.R = R; B.cw_log = A.cw_log;
+            B.src_batch_stride = A.src_batch_stride; B.dst_batch_stride = A.dst_batch_stride;
+            // no row padding: a 512-element tile is 20 KiB of 40-byte records, and eight of them are exactly a CU's 160 KiB — the eight tiles per
+            // CU of a 2^20 transform's pass stay one round of workgroups (with a padding record per row six fit: a second, thin round)
+            static const uint32_t pad29 = getenv("ZKG_NTT29_PAD") ? (uint32_t)atoi(getenv("ZKG_NTT29_PAD")) : 0;              // tuning aid
+            B.row_pad = pad29;
+            hipLaunchKernelGGL(k_ntt_pass29, dim3((unsigned)tiles, batch), dim3(threads), rows * (CW + pad29) * sizeof(Rec29), s, B);
+        } else
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, batch), dim3(threads), lds, s, A);
         if (hipGetLastError() != hipSuccess) { set_error("ntt pass launch failed"); return ZKG_ERROR; }
         s0 += R;

@@ -136,7 +136,7 @@ struct zkg_crs {
     CombTable<zk::Fq> alpha1_comb, beta1_comb, delta1_comb; CombTable<zk::Fq2> delta2_comb;
     zk::NttDomain *dom = nullptr;               // basic_radix2_domain (m = 2^log_m) ...
     zk::StepDomain *sdom = nullptr;             // ... or step_radix2_domain (m = 2^(log_m-1) + 2^b); exactly one is set
-    zk::DevBuf coset_over_m;                    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale
+    zk::DevBuf coset_over_m, coset_over_m29;    // g^i / m : iFFT post-scale fused with the next cosetFFT's pre-scale (and its 29-bit records)
     zk::DevBuf long_rows; uint32_t n_long = 0;  // (matrix << 30 | row) of every row with more than LONG_ROW terms
     zk::Fr z_inv_coset;                         // 1 / (g^m - 1)
     // Prover slots.  A lone caller only ever uses slot 0 (created with the key).  When callers arrive on several threads, a second and a
@@ -326,7 +326,7 @@ static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
         // iFFT then cosetFFT of aA, aB, aC as ONE batch of three (a single 2^18 transform fills half the chip; three fill it):
         // inverse transform with the fused post table g^i/m, then a plain forward transform
         const Fr *fused = crs->coset_over_m.as<Fr>();
-        if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, scr, 3)) return ZKG_ERROR;
+        if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, scr, 3, 0, nullptr, crs->coset_over_m29.p)) return ZKG_ERROR;
         if (ntt_run_ex(crs->dom, aA, false, nullptr, nullptr, nullptr, s, scr, 3)) return ZKG_ERROR;
         hipLaunchKernelGGL(k_pointwise_h, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
         if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, scr)) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
@@ -351,7 +351,7 @@ static int table_window_bits(size_t n) {                                    // w
 static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (S.ready) return ZKG_OK;
     const size_t n = crs->n, m = crs->m;
-    bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * 32) == 0 &&
+    bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * NTT_SCRATCH_BYTES) == 0 &&
               S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(8) == 0 &&
               hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
     if (ok) {
@@ -474,7 +474,8 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = f
     if (ok && crs->dom) {
         Fr g = Fr::from_u64(5);
         crs->z_inv_coset = (g.pow_u64(m) - Fr::one()).inverse();           // basic_radix2_domain::divide_by_Z_on_coset
-        ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0;
+        ok = crs->coset_over_m.reserve(m * 32) == 0 && powers_table(crs->coset_over_m.as<Fr>(), m, g, crs->dom->n_inv, nullptr) == 0 &&
+             ntt_table29(crs->coset_over_m29, crs->coset_over_m.as<Fr>(), m, nullptr) == 0;
     }
     lap("comb tables + domain");
     ok = ok && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) && slot_create(crs, crs->slot[0]) == ZKG_OK;
@@ -492,7 +493,7 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
-                      &crs->coset_over_m, &crs->long_rows})
+                      &crs->coset_over_m, &crs->coset_over_m29, &crs->long_rows})
         b->release();
     for (WindowTable *t : {&crs->H_query, &crs->sub.A, &crs->sub.B1, &crs->sub.B2, &crs->sub.L}) t->release();
     for (DevBuf *b : {&crs->A_query, &crs->B_g1, &crs->B_g2, &crs->L_query, &crs->sub.pos, &crs->sub.idx}) b->release();
