@@ -9,6 +9,7 @@ op) and summed.  One "step" = one full MSM over all N*2^20 points.  Inputs are r
 Prints ONE JSON line (rank 0).  `value` = algorithmic GB/s = 96 B/point * points / wall time.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -33,7 +34,7 @@ def kernel_source_sha16():
     on (tools/pmc_summary.py), and the traffic figure is only reported when it still matches the sources this run was built from"""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("msm.hip", "curve.hip.hpp", "fp.hip.hpp", "mont_asm.inc"):
+    for f in ("msm.hip", "curve.hip.hpp", "fp.hip.hpp", "mont_asm.inc", "fq29.hip.hpp", "f29_asm.inc"):
         with open(os.path.join(ROOT, "zklaim_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
@@ -294,6 +295,7 @@ def main():
     ap.add_argument("--no-northstar", action="store_true", help="skip the second prove leg (37 payloads, m = 2^20: the north star's 2^20-constraint case)")
     ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 37 payloads (the north star's 2^20-constraint case)")
     args = ap.parse_args()
+    gc.disable()        # the interpreter's cyclic collector pauses for tens of ms every few hundred calls (tools/prove_outliers.py): not the product's latency
 
     # stdout carries exactly ONE JSON line: libraries that print banners (RCCL prints its version on first use) go to stderr
     real_stdout = os.dup(1)
@@ -396,25 +398,24 @@ def main():
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
                    "sharding": ("windows sharded per rank (every rank holds all points); " if by_windows else "points sharded per rank; ") + "all-gather of normalised partial points + EC add" if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_bucket_accum<Fq>", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "k_bucket_accum29", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                      "kernel_ms": round(kern_ms, 4), "launches": launches,
-                     "note": "integer-VALU-bound kernel (about 10 Montgomery multiplications per 96 input bytes); see DESIGN.md"},
+                     "note": "integer-VALU-bound kernel (10 Montgomery products of 9 x 29-bit limbs per 96 input bytes and window); see DESIGN.md"},
     }
     if kern_ms > 0:
-        # second, honest roofline for this kernel: vector-ALU issue slots.  One XYZZ mixed addition = 10 Montgomery multiplications of 296
-        # instructions (136 of them half-rate v_mad_u64_u32 / v_mul_lo_u32, counted as 2 slots: 432 slots each) + 8 lazy additions /
-        # subtractions of 35 slots + ~130 of loads, sign handling and zero tests: ~4700 slots; a SIMD retires one full-rate
-        # wave-instruction per ~2.6 cycles at the nominal 2.4 GHz (profiles/r1_microbench_int_issue_rates.txt).  N*W additions per launch,
-        # 64 lanes per wave-instruction.
+        # second, honest roofline for this kernel: vector-ALU issue cycles.  One XYZZ mixed addition on the 29-bit representation issues
+        # 2 224 vector instructions per wavefront (1 549 v_mad_u64_u32), 8 661 cycles at the measured 4.2 cycles per VOP3-encoded and 2.3 per
+        # VOP2-encoded wave-instruction (profiles/r3_mul_variants.txt; counted from the kernel's ISA, tools/r3_pmc_accum.sh gives the same
+        # instruction count from SQ_INSTS_VALU).  N*W additions per launch, 64 lanes per wave-instruction, 4 SIMDs per CU.
         windows = (255 + 15) // 16 if args.logn >= 20 else None
         if windows:
-            slots = n * windows * 4700.0 / 64.0
-            peak_slots_per_s = cus * 4 * 2.4e9 / 2.6
-            line["valu_roofline"] = {"kernel": "k_bucket_accum<Fq>", "mixed_additions_per_launch": n * windows, "issue_slots_per_addition": 4700,
+            cycles = n * windows / 64.0 * 8661.0
+            peak_cycles_per_s = cus * 4 * 2.4e9
+            line["valu_roofline"] = {"kernel": "k_bucket_accum29", "mixed_additions_per_launch": n * windows, "issue_cycles_per_wave_addition": 8661,
                                      "achieved_Gadd_per_s": round(n * windows / (kern_ms * 1e-3) / 1e9, 3),
-                                     "frac_of_issue_peak": round(slots / (kern_ms * 1e-3) / peak_slots_per_s, 4),
-                                     "note": "fraction of the chip's VALU issue capacity at nominal clock; the chip clocks below nominal under this load"}
+                                     "frac_of_issue_peak": round(cycles / (kern_ms * 1e-3) / peak_cycles_per_s, 4),
+                                     "note": "fraction of the SIMDs' issue cycles at the nominal 2.4 GHz; the chip holds ~2.2 GHz under this kernel (profiles/r3_effective_clock_grbm.txt)"}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from the committed
     # rocprofv3 --pmc passes over this same command (tools/pmc_collect.sh -> profiles/pmc_traffic.json), valid for N = 2^20.

@@ -181,6 +181,13 @@ zkg_crs *zkg_crs_upload_blob(const void *pk_blob, size_t len);
  * thrown on (libsnark_wrapper.cpp:160-168) is an error return here. */
 int zkg_pk_blob_inspect(const void *pk_blob, size_t len, uint64_t out[8]);
 void     zkg_crs_free(zkg_crs *crs);
+/* One proof over several GPUs of ONE process: shards the H query of a resident key — the largest of the prover's
+ * four multi-exponentiations, m - 1 uniformly random scalars — by points over `ndev` devices (call zkg_init_multi first; a device may be
+ * listed more than once, which is how a one-GPU box rehearses the path).  Shard i keeps the per-window table of its slice on devices[i];
+ * every later proof copies that slice of coefficients_for_H there (32 bytes per point, peer-to-peer), runs the shards side by side and adds
+ * the partial points on the host.  Everything else of the proof stays on the key's own device.  Proof bytes are unchanged.
+ * No proof of this key may be in flight during the call.                                                                         */
+int zkg_crs_shard_h(zkg_crs *crs, const int *devices, int ndev);
 uint32_t zkg_crs_num_variables(const zkg_crs *crs);   /* n of the resident key (the witness length zkg_groth16_prove expects) */
 
 /* ---- Groth16 prove: r1cs_gg_ppzksnark_prover (snark.cpp:126) with the prover

@@ -378,3 +378,62 @@ def test_concurrent_callers_get_the_serial_proofs(zkg, oracle):
     assert not errors, errors[:5]
     for crs, *_ in jobs:
         crs.free()
+
+
+@pytest.mark.parametrize("shards", [[0, 0], [0, 0, 0], [0] * 8], ids=["2", "3", "8"])
+def test_one_proof_with_the_h_query_sharded(zkg, oracle, shards):
+    """SURVEY §8(e), one proof over several devices from C: zkg_crs_shard_h splits the H query by points (a device listed several times
+    rehearses the path on a one-GPU box: own table, own stream, coefficients copied per shard, partial points summed on the host).
+    Proof bytes must stay those of the unsharded key and of the oracle; sparse witnesses, an unsatisfied witness and callers on
+    two threads included."""
+    import threading
+    from zklaim_amd import synth
+    log_m = 13
+    n, l, A, B, C, w = synth.zklaim_shaped(log_m, num_inputs=5, seed=91)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x5A4B4C41494D0091))
+    rs = [random_fr_canonical(2, 0x5A4B4C41494D0092 + i) for i in range(4)]
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0][0], rs[0][1])
+    assert rc_o == 0
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, log_m, keep))
+    plain = [crs.prove(w, r[0], r[1]) for r in rs]
+    assert plain[0] == (0, proof_o)
+    crs.shard_h(shards)
+    for r, expect in zip(rs, plain):
+        assert crs.prove(w, r[0], r[1]) == expect
+        assert crs.prove(w, r[0], r[1], check_satisfied=False) == expect
+    bad = w.copy(); bad[-1, 0] ^= np.uint64(1)
+    assert crs.prove(bad, rs[0][0], rs[0][1])[0] == zkg.UNSATISFIED
+    assert crs.prove(w, rs[1][0], rs[1][1]) == plain[1]          # the slot is clean after the refused witness
+    errors = []
+
+    def caller(order):
+        for i in order:
+            if crs.prove(w, rs[i][0], rs[i][1]) != plain[i]:
+                errors.append(i)
+
+    threads = [threading.Thread(target=caller, args=(range(4),)), threading.Thread(target=caller, args=(range(3, -1, -1),))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not errors
+    crs.shard_h(shards[:1])                                      # re-sharding replaces the tables; one shard = the whole query on one device
+    assert crs.prove(w, rs[2][0], rs[2][1]) == plain[2]
+    crs.free()
+
+
+def test_h_sharding_rejects_bad_arguments(zkg):
+    case = CASES[0]
+    A, B, C, pts, w, r, s = golden_case_arrays(case)
+    keep = []
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(case["num_variables"], case["num_inputs"], A, B, C, keep), pts, case["m"].bit_length() - 1, keep))
+    with pytest.raises(zkg.ZkgError):
+        crs.shard_h([99])                                        # no such device
+    with pytest.raises(zkg.ZkgError):
+        crs.shard_h([])
+    crs.shard_h([0] * 64)                                        # more shards than H points (m - 1 is tiny here): empty shards are skipped
+    rc, proof = crs.prove(w, r, s)
+    assert rc == 0 and proof.hex() == case["proof_hex"]
+    crs.free()

@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = [
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
-    "zkg_msm_g1_multi", "zkg_g1_add_quad29",
+    "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -327,6 +327,12 @@ class Crs:
         if rc not in (OK, UNSATISFIED):
             _check(rc, "zkg_groth16_prove_sparse")
         return rc, bytes(out[:ln.value])
+
+    def shard_h(self, devices):
+        """zkg_crs_shard_h: the H query's tables sharded by points over `devices` (one GPU listed several times rehearses the path)"""
+        d = (C.c_int * len(devices))(*devices)
+        lib().zkg_crs_shard_h.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _check(lib().zkg_crs_shard_h(C.c_void_p(self._h), d, len(devices)), "zkg_crs_shard_h")
 
     def qap_witness_h(self, witness):
         out = np.zeros((self.m + 1, 4), np.uint64)

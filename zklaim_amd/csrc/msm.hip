@@ -422,11 +422,23 @@ __global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, con
     __syncthreads();
     for (uint32_t i = t; i < nc; i += 1024) if (h[i]) atomicAdd(&class_hist[i], h[i]);
 }
-__global__ void k_class_scan(uint32_t *class_hist, const uint32_t *offsets, size_t total) {       // in place: start position of every class, longest first
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
-    uint32_t run = 0;
-    for (int c = (int)heavy_t + 1; c >= 0; --c) { uint32_t v = class_hist[c]; class_hist[c] = run; run += v; }
+// in place: start position of every class, longest first (one 1024-thread workgroup; class c is scanned at position nc - 1 - c)
+__global__ __launch_bounds__(1024) void k_class_scan(uint32_t *class_hist, const uint32_t *offsets, size_t total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1), nc = heavy_t + 2, t = threadIdx.x;
+    // HEAVY_T_MAX + 2 = 1026 classes at most: thread t takes positions 2t and 2t + 1 of the reversed order
+    uint32_t v0 = 2 * t < nc ? class_hist[nc - 1 - 2 * t] : 0, v1 = 2 * t + 1 < nc ? class_hist[nc - 2 - 2 * t] : 0;
+    part[t] = v0 + v1;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    const uint32_t before = part[t] - v0 - v1;
+    if (2 * t < nc) class_hist[nc - 1 - 2 * t] = before;
+    if (2 * t + 1 < nc) class_hist[nc - 2 - 2 * t] = before + v0;
 }
 __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, const uint32_t *offsets, size_t total, uint32_t *class_cursor, uint32_t *order) {
     __shared__ uint32_t h[HEAVY_T_MAX + 2];
@@ -1110,7 +1122,7 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
     }
     ZK_HIP(hipMemsetAsync(chist, 0, (HEAVY_T_MAX + 2) * 4, s));
     hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist);
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s, chist, offsets, total);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, s, chist, offsets, total);
     hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist, job->order.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) { set_error("msm sort launch failed"); return ZKG_ERROR; }
     return ZKG_OK;

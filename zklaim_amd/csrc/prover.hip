@@ -70,6 +70,9 @@ struct ProverSlot {
     hipStream_t stream = nullptr;               // upload + split + mat-vec + NTT stream
     // witness multi-exponentiations: one job for the three G1 queries (A, B_g1, L share the digit sort), one for B_g2; H on its own
     zk::MsmJob *job_w1 = nullptr, *job_w2 = nullptr, *job_h = nullptr;
+    // H sharded over several devices (zkg_crs_shard_h): this slot's job, scalar slice and "slice copied" event on every shard's device
+    struct HShardRun { int device = 0; zk::MsmJob *job = nullptr; zk::DevBuf scalars; };
+    std::vector<HShardRun> h_runs; uint64_t h_epoch = 0;                       // h_epoch: the sharding (zkg_crs::h_epoch) these were made for
     zk::OnesSum ones_g1, ones_g2;               // flat sums of the bases whose witness element is one: (A, B_g1, L) and B_g2, on streams of their own
     hipStream_t stream_o = nullptr;
     Helper helper;
@@ -124,6 +127,13 @@ struct zkg_crs {
     // The witness queries stay as uploaded (the flat sums over the ones read them) and get tables over a SUBSET of their elements only:
     // the bucket method sees the non-bit variables of a witness, ~3 % of a credential's, and the same ones proof after proof.
     zk::WindowTable H_query;
+    // One proof's H query over several GPUs ("the four MSMs are mutually independent -> task-parallel across GPUs first,
+    // then point-sharding"): H is the largest of the four (m - 1 uniformly random scalars, 40 - 50 % of a proof's critical path at
+    // m >= 2^18) and shards by points exactly like the plain multi-exponentiation: shard i holds the per-window table of its contiguous
+    // slice of the query on devices[i]; a proof copies that slice of coefficients_for_H to it (32 B per point: 4 MiB per shard at m = 2^20
+    // over eight devices), every shard runs the single-GPU table launch on a stream of its own, and the partial points are added on the host.
+    struct HShard { int device = 0; size_t first = 0, n = 0; zk::WindowTable table; };
+    std::vector<HShard> h_shards; int home_device = 0; uint64_t h_epoch = 0;
     zk::DevBuf A_query, B_g1, B_g2, L_query;    // n + 1, n + 1, n + 1 (G2), n - l affine points
     struct SubsetTables {
         std::vector<uint8_t> member;            // host: is element i of z = [1 | w] covered
@@ -490,6 +500,14 @@ zkg_crs *zkg_crs_upload(const zkg_pk *pk) {
 }
 
 
+static void slot_release_h_runs(ProverSlot &S) {                              // leaves the current device changed; callers restore it
+    for (auto &r : S.h_runs) {
+        (void)hipSetDevice(r.device);
+        if (r.job) { (void)hipStreamSynchronize(msm_job_stream(r.job)); msm_job_destroy(r.job); }
+        r.scalars.release();
+    }
+    S.h_runs.clear();
+}
 void zkg_crs_free(zkg_crs *crs) {
     if (!crs) return;
     for (DevBuf *b : {&crs->A.rowptr, &crs->A.col, &crs->A.val, &crs->B.rowptr, &crs->B.col, &crs->B.val, &crs->Cm.rowptr, &crs->Cm.col, &crs->Cm.val,
@@ -497,6 +515,10 @@ void zkg_crs_free(zkg_crs *crs) {
         b->release();
     for (WindowTable *t : {&crs->H_query, &crs->sub.A, &crs->sub.B1, &crs->sub.B2, &crs->sub.L}) t->release();
     for (DevBuf *b : {&crs->A_query, &crs->B_g1, &crs->B_g2, &crs->L_query, &crs->sub.pos, &crs->sub.idx}) b->release();
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (ProverSlot &S : crs->slot) slot_release_h_runs(S);
+    for (auto &sh : crs->h_shards) { (void)hipSetDevice(sh.device); sh.table.release(); }
+    (void)hipSetDevice(cur);
     for (ProverSlot &S : crs->slot) slot_destroy(S);
     delete crs;
 }
@@ -678,6 +700,49 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u)\n", count, n1, T.rebuilds);
     return ZKG_OK;
 }
+// ---- H over several devices: launch (after the transforms, in the slot's stream order) and finish
+static int h_shards_launch(zkg_crs *crs, ProverSlot &S) {
+    int cur = 0; (void)hipGetDevice(&cur);
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{cur};
+    if (S.h_epoch != crs->h_epoch) {                                       // this slot's first proof under this sharding: a job and a buffer per shard
+        slot_release_h_runs(S);
+        S.h_runs.resize(crs->h_shards.size());
+        for (size_t i = 0; i < crs->h_shards.size(); ++i) {
+            ProverSlot::HShardRun &run = S.h_runs[i];
+            run.device = crs->h_shards[i].device;
+            ZK_HIP(hipSetDevice(run.device));
+            run.job = msm_job_create(nullptr, true);
+            if (!run.job || run.scalars.reserve(crs->h_shards[i].n * 32 + 16)) { set_error("prover: H shard workspace"); return ZKG_ERROR; }
+            msm_job_set_window(run.job, crs->h_shards[i].table.c);
+        }
+        S.h_epoch = crs->h_epoch;
+    }
+    // ev[2]: coefficients_for_H complete on the slot's stream (recorded by compute_h_transforms)
+    const Fr *coeff = S.aABC.as<Fr>();
+    for (size_t i = 0; i < crs->h_shards.size(); ++i) {
+        const zkg_crs::HShard &sh = crs->h_shards[i]; ProverSlot::HShardRun &run = S.h_runs[i];
+        ZK_HIP(hipSetDevice(sh.device));
+        hipStream_t st = msm_job_stream(run.job);
+        ZK_HIP(hipStreamWaitEvent(st, S.ev[2], 0));
+        ZK_HIP(hipMemcpyAsync(run.scalars.p, coeff + sh.first, sh.n * 32, hipMemcpyDefault, st));       // peer copy over xGMI (or a device copy on one GPU)
+        const MsmBases h = table_set(sh.table, false, 0);
+        if (msm_job_launch(run.job, &h, 1, run.scalars.as<uint32_t>(), sh.n, true)) return ZKG_ERROR;
+    }
+    return ZKG_OK;
+}
+static int h_shards_finish(zkg_crs *crs, ProverSlot &S, G1 &out) {
+    int cur = 0; (void)hipGetDevice(&cur);
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{cur};
+    out = G1::inf();
+    for (size_t i = 0; i < crs->h_shards.size(); ++i) {
+        ZK_HIP(hipSetDevice(crs->h_shards[i].device));
+        G1 part;
+        if (msm_job_finish(S.h_runs[i].job, &part, nullptr)) return ZKG_ERROR;
+        out.add(part);
+    }
+    return ZKG_OK;
+}
+
 // event slots: 0 witness resident + split done, 1 mat-vec done, 2 H coefficients done, 3 satisfiability flag landed,
 //              4-5 G1 witness job, 6-7 G2 witness job, 8-9 H job
 static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness, const uint64_t r_[4], const uint64_t s_[4], bool check) {
@@ -747,8 +812,11 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     if (rc == ZKG_OK) {
         hipStream_t js = msm_job_stream(S.job_h);                              // == S.stream
         (void)hipEventRecord(S.ev[8], js);
+        if (!crs->h_shards.empty()) rc = h_shards_launch(crs, S);
+        else {
         const MsmBases h = table_set(crs->H_query, false, 0);
         rc = msm_job_launch(S.job_h, &h, 1, S.aABC.as<uint32_t>(), m - 1, true);
+        }
         (void)hipEventRecord(S.ev[9], js);
         if (g_serial_msm) (void)hipStreamSynchronize(js);
     }
@@ -760,6 +828,7 @@ static void slot_drain(const zkg_crs *, ProverSlot &S) {                      //
     (void)hipStreamSynchronize(S.stream);
     for (MsmJob *j : {S.job_w1, S.job_w2, S.job_h}) if (j) (void)hipStreamSynchronize(msm_job_stream(j));
     if (S.stream_o) (void)hipStreamSynchronize(S.stream_o);
+    for (auto &r : S.h_runs) if (r.job) (void)hipStreamSynchronize(msm_job_stream(r.job));
 }
 static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t *proof_len) {
     hipStream_t s = S.stream;
@@ -799,7 +868,7 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     gB2.add(Bt2);
     off += ser_g2(proof_out + off, gB2);
     lap(S, "B serialised");
-    if (msm_job_finish(S.job_h, &Ht, nullptr)) { slot_drain(crs, S); return ZKG_ERROR; }
+    if (crs->h_shards.empty() ? msm_job_finish(S.job_h, &Ht, nullptr) : h_shards_finish(crs, S, Ht)) { slot_drain(crs, S); return ZKG_ERROR; }
     gC.add(Ht);                                                             // C = H_t + L_t + s A + r B_1 - rs delta
     off += ser_g1(proof_out + off, gC);
     *proof_len = off;
@@ -857,6 +926,46 @@ int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint
     try { return groth16_prove_sparse_impl(crs, tags, full_index, full_values, count, r, s, check_satisfied, proof_out, proof_len); }
     catch (const std::exception &e) { set_error(std::string("zkg_groth16_prove_sparse: ") + e.what()); return ZKG_ERROR; }
     catch (...) { set_error("zkg_groth16_prove_sparse: unexpected exception"); return ZKG_ERROR; }
+}
+
+// Shards the H query of a resident key over `ndev` devices (a device may be listed more than once: how a one-GPU box rehearses the
+// path).  No proof of this key may be in flight.  The key's own device keeps everything else (witness queries, transforms, assembly).
+static int crs_shard_h_impl(zkg_crs *crs, const int *devices, int ndev) {
+    if (!crs || !devices || ndev < 1 || ndev > 64) { set_error("zkg_crs_shard_h: bad argument"); return ZKG_ERROR; }
+    int count = 0; (void)hipGetDeviceCount(&count);
+    for (int i = 0; i < ndev; ++i) if (devices[i] < 0 || devices[i] >= count) { set_error("zkg_crs_shard_h: bad device index"); return ZKG_ERROR; }
+    std::unique_lock<std::mutex> lk(crs->mu);
+    if (crs->leases) { set_error("zkg_crs_shard_h: a proof of this key is in flight"); return ZKG_ERROR; }
+    int cur = 0; (void)hipGetDevice(&cur);
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{cur};
+    crs->home_device = cur;
+    const size_t n = crs->H_query.n; const int c = crs->H_query.c;
+    const G1Affine *level0 = crs->H_query.buf.as<G1Affine>();                 // level 0 of the table is the query as uploaded
+    std::vector<zkg_crs::HShard> shards; shards.reserve((size_t)ndev);
+    bool ok = true;
+    for (int i = 0; i < ndev && ok; ++i) {
+        const size_t first = n * (size_t)i / (size_t)ndev, count = n * (size_t)(i + 1) / (size_t)ndev - first;
+        if (!count) continue;                                                  // more shards than points
+        shards.emplace_back();
+        zkg_crs::HShard &sh = shards.back();
+        sh.device = devices[i]; sh.first = first; sh.n = count;
+        ok = hipSetDevice(sh.device) == hipSuccess;
+        if (ok && sh.device != cur) { int can = 0; if (hipDeviceCanAccessPeer(&can, sh.device, cur) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(cur, 0); (void)hipGetLastError(); }
+        ScopedDevBuf slice;
+        ok = ok && slice.reserve(sh.n * sizeof(G1Affine) + 16) == 0 &&
+             hip_ok(hipMemcpy(slice.p, level0 + sh.first, sh.n * sizeof(G1Affine), hipMemcpyDefault), "H shard copy", __FILE__, __LINE__) &&
+             window_table_build_g1(sh.table, slice.as<G1Affine>(), sh.n, c, nullptr) == 0 && window_table_records29(sh.table, nullptr) == 0 &&
+             hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+    }
+    if (!ok) { for (auto &sh : shards) { (void)hipSetDevice(sh.device); sh.table.release(); } return ZKG_ERROR; }
+    crs->h_shards.swap(shards); ++crs->h_epoch;                               // slots rebuild their per-shard jobs at their next proof
+    for (auto &sh : shards) { (void)hipSetDevice(sh.device); sh.table.release(); }     // a previous sharding's tables
+    return ZKG_OK;
+}
+int zkg_crs_shard_h(zkg_crs *crs, const int *devices, int ndev) {
+    try { return crs_shard_h_impl(crs, devices, ndev); }
+    catch (const std::exception &e) { set_error(std::string("zkg_crs_shard_h: ") + e.what()); return ZKG_ERROR; }
+    catch (...) { set_error("zkg_crs_shard_h: unexpected exception"); return ZKG_ERROR; }
 }
 
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
