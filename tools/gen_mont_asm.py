@@ -152,6 +152,13 @@ def main():
         l29.append(f'    "{t}\\n\\t" \\')
     l29.append('    ""')
     l29.append("")
+    ins = gen_f29_dual(False, modulus=F29_R)
+    l29.append(f"// Fr MUL2: {len(ins)} instructions, {sum(1 for t in ins if t.startswith('v_mad'))} v_mad_u64_u32")
+    l29.append("#define ZK_F29R_MUL2_ASM \\")
+    for t in ins:
+        l29.append(f'    "{t}\\n\\t" \\')
+    l29.append('    ""')
+    l29.append("")
     l29.append("#define ZK_F29_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
     l29.append("#define ZK_F29_CLOBBERS2 " + ", ".join([f'"v{i}"' for i in range(2, 13)] + [f'"v{i}"' for i in range(14, 25)] + [f'"s{i}"' for i in range(16, 27)] + ['"vcc"']))
     open(dst29, "w").write("\n".join(l29) + "\n")
@@ -311,16 +318,16 @@ def gen_f29(square, col=2, m0=4, out0=0, a0=9, b0=18, consts=True, modulus=None)
     return out
 
 
-def gen_f29_dual(square):
+def gen_f29_dual(square, modulus=None):
     """two independent products, instruction by instruction: each chain's next multiply-add issues while the other's is in flight (a lone
     column is a chain of dependent v_mad_u64_u32; at two wavefronts per SIMD its latency shows).  Operands: %0-%8 and %9-%17 the results,
     %18-%26 a, %27-%35 b (first product), %36-%44 c, %45-%53 d (second product)."""
-    q = F29_P
+    q = modulus or F29_P
     P = [(q >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
     inv = (-pow(q, -1, 1 << 29)) % (1 << 29)
     head = [f"s_mov_b32 s25, 0x{inv:08x}", "s_mov_b32 s26, 0x1fffffff"] + [f"s_mov_b32 s{16 + j}, 0x{P[j]:08x}" for j in range(9)]
-    x = gen_f29(square, col=2, m0=4, out0=0, a0=18, b0=27, consts=False)
-    y = gen_f29(square, col=14, m0=16, out0=9, a0=36, b0=45, consts=False)
+    x = gen_f29(square, col=2, m0=4, out0=0, a0=18, b0=27, consts=False, modulus=modulus)
+    y = gen_f29(square, col=14, m0=16, out0=9, a0=36, b0=45, consts=False, modulus=modulus)
     body = []
     for i in range(max(len(x), len(y))):
         if i < len(x):
@@ -386,6 +393,14 @@ def selftest_f29():
         a = rnd.randrange(60 * F29_R); b = rnd.randrange(F29_R)
         got = value(simulate_f29(mul_r, {**ops(9, limbs(a)), **ops(18, limbs(b))}))
         assert got < 2 * F29_R and got % F29_R == a * b * rinv_r % F29_R, ("mul Fr", t)
+    mul2_r = gen_f29_dual(False, modulus=F29_R)
+    for t in range(200):                                                         # Fr pairs, the radix-4 butterflies' operands: limbs up to 2.5 x 2^30 on the a side (two lazy stages)
+        a = [x + rnd.choice((0, 1 << 30, 3 << 29, 1 << 31)) if i < 8 else x for i, x in enumerate(limbs(rnd.randrange(2 * F29_R)))]
+        c = [(5 << 29) - 1] * 8 + [1 << 27] if t == 0 else [x + (1 << 30) if i < 8 else x for i, x in enumerate(limbs(rnd.randrange(50 * F29_R)))]
+        b, d = rnd.randrange(F29_R), rnd.randrange(F29_R)
+        r = simulate_f29(mul2_r, {**ops(18, a), **ops(27, limbs(b)), **ops(36, c), **ops(45, limbs(d))}, 18)
+        assert value(r[:9]) % F29_R == value(a) * b * rinv_r % F29_R and value(r[9:]) % F29_R == value(c) * d * rinv_r % F29_R, ("mul2 Fr", t)
+        assert value(r[:9]) < 2 * F29_R and value(r[9:]) < 2 * F29_R and all(x < 1 << 29 for x in r[:8] + r[9:17]), ("mul2 Fr range", t)
     for t in range(300):
         a = rnd.randrange(13 * q) if t > 3 else [0, 1, q - 1, 13 * q - 1][t]
         b = rnd.randrange(13 * q) if t > 3 else [0, q - 1, q - 1, 13 * q - 1][t]

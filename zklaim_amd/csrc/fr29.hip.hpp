@@ -36,6 +36,27 @@ ZK_D Fr29 mul(const Fr29 &a, const Fr29 &b) {
         : ZK_F29_CLOBBERS);
     return t;
 }
+// two independent products, interleaved instruction by instruction (gen_f29_dual with Fr's modulus): a, c limbs up to 2.5 x 2^30
+ZK_D void mul2(Fr29 &r0, Fr29 &r1, const Fr29 &a, const Fr29 &b, const Fr29 &c, const Fr29 &d) {
+#define ZK_FR29_IN9(x) "v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]), "v"(x.v[4]), "v"(x.v[5]), "v"(x.v[6]), "v"(x.v[7]), "v"(x.v[8])
+    asm(ZK_F29R_MUL2_ASM
+        : "=&v"(r0.v[0]), "=&v"(r0.v[1]), "=&v"(r0.v[2]), "=&v"(r0.v[3]), "=&v"(r0.v[4]), "=&v"(r0.v[5]), "=&v"(r0.v[6]), "=&v"(r0.v[7]), "=&v"(r0.v[8]),
+          "=&v"(r1.v[0]), "=&v"(r1.v[1]), "=&v"(r1.v[2]), "=&v"(r1.v[3]), "=&v"(r1.v[4]), "=&v"(r1.v[5]), "=&v"(r1.v[6]), "=&v"(r1.v[7]), "=&v"(r1.v[8])
+        : ZK_FR29_IN9(a), ZK_FR29_IN9(b), ZK_FR29_IN9(c), ZK_FR29_IN9(d)
+        : ZK_F29_CLOBBERS2);
+#undef ZK_FR29_IN9
+}
+// limb-wise u + t and u + 2r - t without carries (the radix-4 butterflies normalise once per two stages): t digits below 1.36 r (a product
+// of a value below 60 r with a twiddle below r), so its top limb stays below S2_1's; the results' limbs grow by 2^29 resp. 2^30.
+ZK_D Fr29 add_lazy(const Fr29 &a, const Fr29 &b) { Fr29 r; for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+ZK_D Fr29 sub_lazy(const Fr29 &a, const Fr29 &b) { Fr29 r; for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + S2_1[i] - b.v[i]; return r; }
+ZK_D Fr29 norm(const Fr29 &a) {                               // carry propagation: limbs below 2^32 in, digits out
+    Fr29 r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint32_t t = a.v[i] + c; r.v[i] = t & Fr29::M; c = t >> 29; }
+    r.v[8] = a.v[8] + c;
+    return r;
+}
 // u + t and u + 2r - t as digits (t: digits below 2r - 2^232; u: digits)
 ZK_D Fr29 add_norm(const Fr29 &a, const Fr29 &b) {
     Fr29 r; uint32_t c = 0;

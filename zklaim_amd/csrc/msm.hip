@@ -122,8 +122,14 @@ ZK_D uint32_t bits_at(const uint32_t v[8], uint32_t off, uint32_t c) {
 }
 
 // digit code: 0 = no contribution; otherwise ((bucket + 1) << 1) | negative, bucket = |d| - 1
-__global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, const uint32_t *gather, size_t n, int mont, MsmGeom g, uint32_t *digits) {
+// The job's first kernel also clears the counters its later kernels accumulate into (coarse-bin counts, class histogram, heavy-bucket
+// counters): three hipMemsetAsync fill launches per job were three more dependent launches on a proof's critical path.
+struct ZeroList { uint32_t *p[4]; uint32_t words[4]; };
+__global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, const uint32_t *gather, size_t n, int mont, MsmGeom g, uint32_t *digits, ZeroList zl) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) for (size_t z = i; z < zl.words[k]; z += lanes) zl.p[k][z] = 0;
     if (i >= n) return;
     Fr f;
     const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * (gather ? (size_t)gather[i] : i));
@@ -854,20 +860,40 @@ __global__ __launch_bounds__(256) void k_scatter_points(const Affine<F> *src, co
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < count) out[idx[j]] = src[j];
 }
+// A workgroup owns `span` consecutive tags.  Its four wavefronts first list the positions tagged 1 in LDS (ballot + prefix count, a segment
+// per wavefront: the order is the index order, nothing depends on timing), then all 256 lanes stride over the list — every lane of every
+// addition is a real one.  (Round 2 strode over the tags themselves: with half the witness bits zero half of each wavefront's additions were
+// masked off, the kernel's time was twice its work.)
 template <class F>
-__global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const uint8_t *tags, size_t n1, XYZZ<F> *partials) {
+__global__ __launch_bounds__(256) void k_ones_sum(const ViewSet<F> views, const uint8_t *tags, size_t n1, uint32_t span, XYZZ<F> *partials) {
     extern __shared__ unsigned char red_smem[];
     LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);            // 256 points
+    uint32_t *list = reinterpret_cast<uint32_t *>(red_smem + 256 * sizeof(LdsPoint<F>));        // span positions, span / 4 per wavefront
+    __shared__ uint32_t seg_count[4];
     const Affine<F> *bases = views.v[blockIdx.y].p; const uint32_t index_sub = views.v[blockIdx.y].index_sub;
     partials += (size_t)blockIdx.y * (gridDim.x + 1);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride)
-        if (i >= index_sub && tags[i] == 1) acc.madd(bases[i - index_sub]);
-    sh[threadIdx.x] = acc;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cap = span >> 2;
+    const size_t first = (size_t)blockIdx.x * span + (size_t)wv * cap;
+    uint32_t count = 0;                                                       // uniform across the wavefront
+    for (uint32_t o = 0; o < cap; o += 64) {
+        const size_t i = first + o + lane;
+        const bool one = i < n1 && i >= index_sub && tags[i] == 1;
+        const unsigned long long mask = __ballot(one);
+        if (one) list[wv * cap + count + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint32_t)(i - index_sub);
+        count += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) seg_count[wv] = count;
     __syncthreads();
-    lds_tree_reduce<F>(sh, 256, threadIdx.x, 256, [] { __syncthreads(); });
-    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0].normalized();
+    const uint32_t c0 = seg_count[0], c1 = c0 + seg_count[1], c2 = c1 + seg_count[2], total = c2 + seg_count[3];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t k = tid; k < total; k += 256) {
+        const uint32_t seg = (k >= c0) + (k >= c1) + (k >= c2), off = seg == 0 ? 0u : (seg == 1 ? c0 : (seg == 2 ? c1 : c2));
+        acc.madd(bases[list[seg * cap + (k - off)]]);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    lds_tree_reduce<F>(sh, 256, tid, 256, [] { __syncthreads(); });
+    if (tid == 0) partials[blockIdx.x] = sh[0].normalized();
 }
 template <class F>
 __global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uint32_t count) {        // per set: partials[0..count) -> partials[count]
@@ -937,7 +963,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
         gr.buckets.reserve(ns * total_buckets * sizeof(XYZZ<F>)) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
         (gr.table && gr.folded.reserve(ns * (size_t)g.B * sizeof(XYZZ<F>))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
-    ZK_HIP(hipMemsetAsync(gr.heavy_counters.p, 0, 8 * MSM_MAX_SETS, s));
+    // (gr.heavy_counters: cleared by the job's k_digits)
     XYZZ<F> *buckets = gr.buckets.as<XYZZ<F>>();
     ViewSet<F> views;
     for (unsigned i = 0; i < (unsigned)MSM_MAX_SETS; ++i) {
@@ -1091,7 +1117,6 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
         job->order.reserve(total * 4) || job->sorted.reserve(std::max<size_t>(1, n * g.W) * 4)) return ZKG_ERROR;
     uint32_t *digits = job->digits.as<uint32_t>(), *hist = job->hist.as<uint32_t>(), *counts = job->counts.as<uint32_t>(),
              *offsets = job->offsets.as<uint32_t>(), *sums = job->scan_sums.as<uint32_t>(), *chist = job->class_hist.as<uint32_t>();
-    if (n) hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_gather, n, (int)mont, g, digits);
     static const bool radix_off = getenv("ZKG_SORT_ONE_PASS") != nullptr;                       // A/B switch
     uint32_t cbits = 6;
     static const uint32_t bin_avg = getenv("ZKG_RX_AVG") ? (uint32_t)atoi(getenv("ZKG_RX_AVG")) : RX_BIN_AVG;     // tuning aid
@@ -1099,12 +1124,26 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
     // (below ~2^15.5 points the one-pass sort's six small launches beat the two-pass sort's eleven: a one-payload proof's H query, 2^15 - 1
     //  points, 0.657 -> 0.603 ms; equal at 2^16, the two-pass sort 5 % ahead at 2^17)
     const bool two_pass = !radix_off && !job->one_pass_sort && g.c >= 12 && n >= 49152 && (n >> cbits) <= RX_FINE_MAX && n <= ((size_t)1 << (31 - (g.c - 1 - cbits)));
+    {
+        ZeroList zl{};
+        int k = 0;
+        zl.p[k] = chist; zl.words[k++] = HEAVY_T_MAX + 2;
+        for (MsmGroup &gr : job->group) if (gr.nsets) {
+            if (gr.heavy_counters.reserve(8 * MSM_MAX_SETS)) return ZKG_ERROR;
+            zl.p[k] = gr.heavy_counters.as<uint32_t>(); zl.words[k++] = 2 * MSM_MAX_SETS;
+        }
+        if (two_pass) {
+            const uint32_t nbins = g.W << cbits;
+            if (job->rx_meta.reserve((3 * (size_t)nbins + 8) * 4)) return ZKG_ERROR;
+            zl.p[k] = job->rx_meta.as<uint32_t>(); zl.words[k++] = 3 * nbins + 8;
+        }
+        hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_gather, n, (int)mont, g, digits, zl);   // n >= 1 (msm_job_launch)
+    }
     if (two_pass) {
         // two-pass sort: 2^cbits coarse bins per window, then the remaining fbits inside LDS
         const uint32_t fbits = g.c - 1 - cbits, CB = 1u << cbits, nbins = g.W * CB, S1 = (uint32_t)((n + RX_SLICE - 1) / RX_SLICE);
         if (job->rx_tmp.reserve(n * g.W * 4) || job->rx_meta.reserve((3 * (size_t)nbins + 8) * 4)) return ZKG_ERROR;
         uint32_t *cnt = job->rx_meta.as<uint32_t>(), *base = cnt + nbins, *cursor = base + nbins + 1, *tmp = job->rx_tmp.as<uint32_t>();
-        ZK_HIP(hipMemsetAsync(cnt, 0, (3 * (size_t)nbins + 8) * 4, s));
         hipLaunchKernelGGL(k_rx_count, dim3(S1, g.W), dim3(1024), 0, s, digits, n, fbits, cbits, cnt);
         hipLaunchKernelGGL(k_rx_scan, dim3(1), dim3(1024), 0, s, cnt, nbins, base, cursor, offsets + total);
         hipLaunchKernelGGL(k_rx_scatter, dim3(S1, g.W), dim3(1024), (RX_SLICE + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
@@ -1120,7 +1159,6 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(1024), 0, s, offsets, sums, total);
     hipLaunchKernelGGL(k_place, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist, offsets, job->sorted.as<uint32_t>());
     }
-    ZK_HIP(hipMemsetAsync(chist, 0, (HEAVY_T_MAX + 2) * 4, s));
     hipLaunchKernelGGL(k_class_hist, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, s, chist, offsets, total);
     hipLaunchKernelGGL(k_order_place, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, counts, offsets, total, chist, job->order.as<uint32_t>());
@@ -1275,17 +1313,18 @@ int scatter_points_g1(const G1Affine *d_src, const uint32_t *d_idx, size_t count
 int scatter_points_g2(const G2Affine *d_src, const uint32_t *d_idx, size_t count, G2Affine *d_out, hipStream_t s) { return scatter_points_t<Fq2>(d_src, d_idx, count, d_out, s); }
 template <class F>
 static int ones_sum_launch_t(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *d_tags, size_t n1, hipStream_t s) {
-    // lanes stride over the tags; per workgroup an 8-level LDS tree; one more workgroup per set sums the partials.  ~8 tagged elements per
-    // lane: the kernel is a dependency chain (lane-local additions, then the two trees), so more lanes than that only lengthen the second tree.
+    // per workgroup: list the positions tagged 1, lanes stride over the list, an 8-level LDS tree; one more workgroup per set sums the partials
     if (nsets < 1 || nsets > MSM_MAX_SETS) { set_error("ones-sum: bad set count"); return ZKG_ERROR; }
-    const unsigned blocks = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (n1 + 2047) / 2048));
+    // tags per workgroup: a 256th of the vector, at least 1024 (a short list per lane leaves only the trees) and at most 8192 (32 KiB of LDS list)
+    const uint32_t span = (uint32_t)std::min<size_t>(8192, std::max<size_t>(1024, ((n1 + 255) / 256 + 255) / 256 * 256));
+    const unsigned blocks = (unsigned)std::max<size_t>(1, (n1 + span - 1) / span);
     o.g2 = sizeof(F) != sizeof(Fq); o.nsets = nsets;
     if (o.partials.reserve((size_t)nsets * (blocks + 1) * sizeof(XYZZ<F>))) return ZKG_ERROR;
     if (!o.host) { if (!hip_ok(hipHostMalloc(&o.host, MSM_MAX_SETS * sizeof(G2), hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__)) return ZKG_ERROR; }
     XYZZ<F> *part = o.partials.as<XYZZ<F>>();
     ViewSet<F> views;
     for (int i = 0; i < MSM_MAX_SETS; ++i) { const MsmBases &b = sets[i < nsets ? i : 0]; views.v[i] = BaseView<F>{reinterpret_cast<const Affine<F> *>(b.p), 0, nullptr, b.index_sub, 1, nullptr}; }
-    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, views, d_tags, n1, part);
+    hipLaunchKernelGGL(k_ones_sum<F>, dim3(blocks, (unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>) + (size_t)span * 4, s, views, d_tags, n1, span, part);
     hipLaunchKernelGGL(k_sum_partials<F>, dim3((unsigned)nsets), dim3(256), 256 * sizeof(LdsPoint<F>), s, part, blocks);
     if (hipGetLastError() != hipSuccess) { set_error("ones-sum launch failed"); return ZKG_ERROR; }
     for (int i = 0; i < nsets; ++i)
@@ -1398,7 +1437,8 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_parts<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_heavy_merge<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_bucket_fold<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_THREADS * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>) + 8192 * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_ones_sum<Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq>) + 8192 * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;

@@ -4,12 +4,13 @@
 // (_basic_serial_radix2_FFT, _multiply_by_coset), reached from r1cs_to_qap_witness_map inside
 // r1cs_gg_ppzksnark_prover (/root/reference/zklaim/snark.cpp:126).
 //
-// Shape: the log2(N) butterfly stages are cut into passes of R <= 8 stages.  One workgroup
-// stages a tile of 2^R rows x CW columns (512 or 1024 elements = 16 / 32 KiB, so several tiles share a CU) in LDS, runs its
-// R stages there and writes the tile back, so a 2^20 transform touches HBM 3 times instead of 20.  The
+// Shape: the log2(N) butterfly stages are cut into passes of R <= 10 stages (R <= 8 below 2^18).  One workgroup
+// stages a tile of 2^R rows x CW columns (1024 elements = 40 KiB of 29-bit records, 512 below 2^18: several tiles share a CU) in LDS, runs
+// its R stages there and writes the tile back, so a 2^20 transform touches HBM twice instead of 20 times.  The
 // bit-reversal permutation is folded into the first pass's gather (reads stay CW*32 B contiguous),
 // coset / 1/N scalings are folded into the first load / last store.  Twiddles come from a
-// per-domain table omega^i (i < N/2) that stays L2/MALL resident.
+// per-domain table omega^i (i < N/2) that stays L2/MALL resident.  Workgroups are dealt round-robin over the 8 XCDs, so tile t is given
+// to workgroup 8 (t mod tiles/8) + t / (tiles/8): the tiles one XCD's L2 sees are neighbours in memory.
 // MFMA is not used: the work is 254-bit modular multiplication on the integer VALU.
 #include "common.hpp"
 #include "fr29.hip.hpp"
@@ -23,7 +24,7 @@ namespace zk {
 
 static constexpr int NTT_THREADS = 512;
 static const int NTT_TILE_LOG_FORCE = getenv("ZKG_NTT_TILE_LOG") ? atoi(getenv("ZKG_NTT_TILE_LOG")) : 0;   // tuning aid
-static const int NTT_MAX_R = getenv("ZKG_NTT_MAX_R") ? atoi(getenv("ZKG_NTT_MAX_R")) : 8;                                // stages per pass (tuning aid)
+static const int NTT_MAX_R_FORCE = getenv("ZKG_NTT_MAX_R") ? atoi(getenv("ZKG_NTT_MAX_R")) : 0;                          // stages per pass (tuning aid)
 
 struct alignas(16) U4 { uint32_t a, b, c, d; };
 
@@ -94,13 +95,16 @@ struct NttPassArgs29 {
     const void *src; void *dst; const Rec29 *tw, *pre, *post;
     uint32_t post_scalar[9];
     uint32_t n_log, s0, R, cw_log, first, last, has_post_scalar, row_pad;      // row_pad: records of padding per LDS row
+    uint32_t xcd_tiles;                                                        // tiles per XCD (0 = identity map)
     size_t src_batch_stride, dst_batch_stride;      // elements between the vectors of a batch (blockIdx.y), in the units of src / dst
 };
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
     extern __shared__ U4 smem[];
     Rec29 *lds = reinterpret_cast<Rec29 *>(smem);
     const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = CW + A.row_pad;
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x, nthr = blockDim.x;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    // workgroups are dealt round-robin over the 8 XCDs: with xcd_tiles set, the tiles one XCD works on are neighbours in memory
+    const uint32_t tile = A.xcd_tiles ? (blockIdx.x & 7u) * A.xcd_tiles + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t s1 = A.s0 + A.R;
     const uint32_t lo_mask = (1u << A.s0) - 1;
     const Fr *src_abi = reinterpret_cast<const Fr *>(A.src) + (size_t)blockIdx.y * A.src_batch_stride;
@@ -147,6 +151,89 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
         Fr29 v = fr29::load_rec(lds + mid * stride + c);
         if (!A.last) { fr29::store_rec(dst_rec + idx, v); continue; }
         Fr29 f;                                                      // the last product: post table, 1/N, or one — below 2r either way
+        if (A.post) f = fr29::load_rec(A.post + idx);
+        else if (A.has_post_scalar) { for (int i = 0; i < 9; ++i) f.v[i] = A.post_scalar[i]; }
+        else { for (int i = 0; i < 9; ++i) f.v[i] = fr29::ONE[i]; }
+        dst_abi[idx] = fr29::unslice_reduce(fr29::mul(v, f));
+    }
+}
+// ---- the same pass with radix-4 steps: a thread takes four rows r, r + h, r + 2h, r + 3h of one column through stages q and q + 1 in
+//      registers (four products as two interleaved pairs, three twiddles), so a tile makes R / 2 round trips through LDS instead of R, with
+//      half the barriers, and the additions / subtractions between the two stages are limb-wise: one carry propagation per element per
+//      step instead of one per stage.  Limb bounds: stage q: x + t < 2^30, x + 2r - t < 1.5 x 2^30 (these feed stage q + 1's products: the
+//      stream takes limbs up to 2.5 x 2^30, tools/gen_mont_asm.py selftest_f29); stage q + 1: below 2.5 x 2^30.  An odd R ends with one radix-2 step.
+__global__ __launch_bounds__(256) void k_ntt_pass29_r4(NttPassArgs29 A) {
+    extern __shared__ U4 smem[];
+    Rec29 *lds = reinterpret_cast<Rec29 *>(smem);
+    const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = CW + A.row_pad;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t tile = A.xcd_tiles ? (blockIdx.x & 7u) * A.xcd_tiles + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t s1 = A.s0 + A.R;
+    const uint32_t lo_mask = (1u << A.s0) - 1;
+    const Fr *src_abi = reinterpret_cast<const Fr *>(A.src) + (size_t)blockIdx.y * A.src_batch_stride;
+    const Rec29 *src_rec = reinterpret_cast<const Rec29 *>(A.src) + (size_t)blockIdx.y * A.src_batch_stride;
+    Fr *dst_abi = reinterpret_cast<Fr *>(A.dst) + (size_t)blockIdx.y * A.dst_batch_stride;
+    Rec29 *dst_rec = reinterpret_cast<Rec29 *>(A.dst) + (size_t)blockIdx.y * A.dst_batch_stride;
+
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {               // load tile
+        uint32_t c = e & (CW - 1), mid = e >> A.cw_log;
+        size_t idx; uint32_t row;
+        if (A.first) { idx = (size_t)mid * ((size_t)1 << (A.n_log - A.R)) + (size_t)tile * CW + c; row = bitrev(mid, A.R); }
+        else { uint32_t g = tile * CW + c; idx = ((size_t)(g >> A.s0) << s1) + ((size_t)mid << A.s0) + (g & lo_mask); row = mid; }
+        Fr29 v = A.first ? fr29::slice(src_abi[idx]) : fr29::load_rec(src_rec + idx);
+        if (A.pre) v = fr29::mul(v, fr29::load_rec(A.pre + idx));
+        fr29::store_rec(lds + row * stride + c, v);
+    }
+    __syncthreads();
+
+    uint32_t q = 0;
+    for (; q + 1 < A.R; q += 2) {                                     // radix-4 steps: stages s0 + q and s0 + q + 1
+        const uint32_t s = A.s0 + q, h = 1u << q;
+        for (uint32_t qd = tid; qd < (rows >> 2) * CW; qd += nthr) {
+            const uint32_t c = qd & (CW - 1), k = qd >> A.cw_log;
+            const uint32_t j = k & (h - 1), r0 = ((k >> q) << (q + 2)) | j;
+            Rec29 *p0 = lds + r0 * stride + c, *p1 = p0 + h * stride, *p2 = p1 + h * stride, *p3 = p2 + h * stride;
+            const uint32_t lo = A.first ? 0u : ((tile * CW + c) & lo_mask);
+            const size_t eb = ((size_t)((j << A.s0) + lo)) << (A.n_log - 2 - s);              // stage s + 1, row bits j
+            const Fr29 wb = fr29::load_rec(A.tw + eb), wc = fr29::load_rec(A.tw + eb + ((size_t)1 << (A.n_log - 2)));   // ... and row bits j + h: (h << s0) << (n - 2 - s) = N / 4 further
+            const Fr29 x0 = fr29::load_rec(p0), x2 = fr29::load_rec(p2);
+            Fr29 t1 = fr29::load_rec(p1), t3 = fr29::load_rec(p3);
+            if (s != 0) { const Fr29 wa = fr29::load_rec(A.tw + 2 * eb); fr29::mul2(t1, t3, t1, wa, t3, wa); }
+            const Fr29 y0 = fr29::add_lazy(x0, t1), y1 = fr29::sub_lazy(x0, t1), y2 = fr29::add_lazy(x2, t3), y3 = fr29::sub_lazy(x2, t3);
+            Fr29 u2, u3;
+            fr29::mul2(u2, u3, y2, wb, y3, wc);
+            fr29::store_rec(p0, fr29::norm(fr29::add_lazy(y0, u2)));
+            fr29::store_rec(p2, fr29::norm(fr29::sub_lazy(y0, u2)));
+            fr29::store_rec(p1, fr29::norm(fr29::add_lazy(y1, u3)));
+            fr29::store_rec(p3, fr29::norm(fr29::sub_lazy(y1, u3)));
+        }
+        __syncthreads();
+    }
+    if (q < A.R) {                                                    // odd R: the last stage alone
+        const uint32_t s = A.s0 + q, half = 1u << q;
+        for (uint32_t bf = tid; bf < (rows >> 1) * CW; bf += nthr) {
+            uint32_t c = bf & (CW - 1), k = bf >> A.cw_log;
+            uint32_t j = k & (half - 1), r0 = ((k >> q) << (q + 1)) | j, r1 = r0 + half;
+            const Fr29 u = fr29::load_rec(lds + r0 * stride + c);
+            Fr29 v = fr29::load_rec(lds + r1 * stride + c);
+            if (s != 0) {
+                uint32_t lo = A.first ? 0u : ((tile * CW + c) & lo_mask);
+                size_t e = ((size_t)((j << A.s0) + lo)) << (A.n_log - 1 - s);
+                v = fr29::mul(v, fr29::load_rec(A.tw + e));
+            }
+            fr29::store_rec(lds + r0 * stride + c, fr29::add_norm(u, v));
+            fr29::store_rec(lds + r1 * stride + c, fr29::sub_norm(u, v));
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t e = tid; e < rows * CW; e += nthr) {               // store tile
+        uint32_t c, mid; size_t idx;
+        if (A.first) { mid = e & (rows - 1); c = e >> A.R; idx = ((size_t)bitrev(tile * CW + c, A.n_log - A.R) << A.R) + mid; }
+        else { c = e & (CW - 1); mid = e >> A.cw_log; uint32_t g = tile * CW + c; idx = ((size_t)(g >> A.s0) << s1) + ((size_t)mid << A.s0) + (g & lo_mask); }
+        Fr29 v = fr29::load_rec(lds + mid * stride + c);
+        if (!A.last) { fr29::store_rec(dst_rec + idx, v); continue; }
+        Fr29 f;
         if (A.post) f = fr29::load_rec(A.post + idx);
         else if (A.has_post_scalar) { for (int i = 0; i < 9; ++i) f.v[i] = A.post_scalar[i]; }
         else { for (int i = 0; i < 9; ++i) f.v[i] = fr29::ONE[i]; }
@@ -240,7 +327,8 @@ NttDomain *ntt_domain(unsigned logn, hipStream_t s) {
 }
 int ntt_configure() {
     return hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-           hipFuncSetAttribute((const void *)k_ntt_pass29, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? ZKG_OK : ZKG_ERROR;
+           hipFuncSetAttribute((const void *)k_ntt_pass29, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void *)k_ntt_pass29_r4, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? ZKG_OK : ZKG_ERROR;
 }
 void ntt_release_all() {
     std::lock_guard<std::mutex> lk(g_dom_mu);
@@ -261,10 +349,14 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
     if (post && !post29 && post == d->icoset_post.as<Fr>()) post29 = d->icoset_post29.p;
     static const bool ntt32 = getenv("ZKG_NTT_32") != nullptr;                                          // A/B switch
     const bool use29 = !ntt32 && (!pre || pre29) && (!post || post29);
-    // elements per workgroup tile, measured (MI355X): 512 up to 2^20 (2^18: 0.057 ms against 0.099 ms with 2048-element tiles:
-    // four times as many workgroups and 4+ of them per CU, so one tile's loads run under another's butterflies), 1024 above;
-    // one thread per butterfly of a stage
-    const int NTT_TILE_LOG = NTT_TILE_LOG_FORCE ? NTT_TILE_LOG_FORCE : (n <= 20 ? 9 : 10);
+    // geometry, measured (MI355X, profiles/r3_ntt_geometry.txt): passes of up to 10 stages over 1024-element tiles (40 KiB of LDS records, four
+    // workgroups per CU), radix-4 steps, XCD-contiguous tile map — 2^20 in two passes: 0.131 ms against 0.145 ms for round 2's three passes
+    // of 7 + 7 + 6 radix-2 stages over 512-element tiles (ZKG_NTT_MAX_R=8 ZKG_NTT_TILE_LOG=9 ZKG_NTT_RADIX2=1 ZKG_NTT_XCD=0)
+    // Below 2^18 there are too few 1024-element tiles for the chip (2^16: 0.029 ms with 512-element tiles and a thread per butterfly, 0.035 ms
+    // with the large geometry): those keep round 2's shape.
+    const bool large = n >= 18;
+    const int NTT_TILE_LOG = NTT_TILE_LOG_FORCE ? NTT_TILE_LOG_FORCE : (large ? 10 : 9);
+    const unsigned NTT_MAX_R = NTT_MAX_R_FORCE ? (unsigned)NTT_MAX_R_FORCE : (large ? 10u : 8u);
     unsigned npass = (n + NTT_MAX_R - 1) / NTT_MAX_R;
     if (n <= (unsigned)NTT_TILE_LOG) npass = 1;
     unsigned base = n / npass, extra = n % npass;
@@ -309,6 +401,13 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
             // CU of a 2^20 transform's pass stay one round of workgroups (with a padding record per row six fit: a second, thin round)
             static const uint32_t pad29 = getenv("ZKG_NTT29_PAD") ? (uint32_t)atoi(getenv("ZKG_NTT29_PAD")) : 0;              // tuning aid
             B.row_pad = pad29;
+            static const bool xcd_map = !getenv("ZKG_NTT_XCD") || atoi(getenv("ZKG_NTT_XCD")) != 0;
+            B.xcd_tiles = (xcd_map && tiles % 8 == 0) ? (uint32_t)(tiles / 8) : 0;
+            static const int radix_force = getenv("ZKG_NTT_RADIX2") ? (atoi(getenv("ZKG_NTT_RADIX2")) ? 2 : 4) : 0;          // A/B switch
+            if (radix_force ? radix_force == 4 : large) {
+                const unsigned threads4 = (unsigned)std::min<size_t>(256, std::max<size_t>(64, rows * CW / 4));             // one thread per four rows of a column
+                hipLaunchKernelGGL(k_ntt_pass29_r4, dim3((unsigned)tiles, batch), dim3(threads4), rows * (CW + pad29) * sizeof(Rec29), s, B);
+            } else
             hipLaunchKernelGGL(k_ntt_pass29, dim3((unsigned)tiles, batch), dim3(threads), rows * (CW + pad29) * sizeof(Rec29), s, B);
         } else
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, batch), dim3(threads), lds, s, A);

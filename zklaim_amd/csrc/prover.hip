@@ -212,10 +212,17 @@ __global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_
     }
     if (lane == 0) (mtx == 0 ? aA : mtx == 1 ? aB : aC)[row] = acc.normalized();
 }
-// flag |= 1 when a row violates <A,z><B,z> = <C,z>: the pb.is_satisfied() gate of snark.cpp:121-124
-__global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, const Fr *aC, uint32_t C, uint32_t *flag) {
+// Device-scope atomics only (no fence: a release fence writes back the XCD's whole L2, and one per workgroup behind the mat-vec's 96 MB of
+// fresh output doubled that stage at 2^20): the OR returns its old value and the lane waits for it, so it has been performed before the
+// workgroup's barrier and ticket.
+ZK_D void or_and_wait(uint32_t *word) { const uint32_t old = atomicOr(word, 1u); asm volatile("" : : "v"(old) : "memory"); }
+// flag[0] |= 1 when a row violates <A,z><B,z> = <C,z>: the pb.is_satisfied() gate of snark.cpp:121-124.  The last workgroup to finish
+// (ticket in flag[1]) writes the verdict straight into the caller's pinned word: no copy launch between the mat-vec and the transforms.
+__global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, const Fr *aC, uint32_t C, uint32_t *flag, uint32_t *host_flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C && aA[i] * aB[i] != aC[i]) atomicOr(flag, 1u);
+    if (i < C && aA[i] * aB[i] != aC[i]) or_and_wait(flag);
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(flag + 1, 1u) == gridDim.x - 1) host_flag[0] = atomicOr(flag, 0u);
 }
 
 // the same on a step_radix2_domain: Z(g x_i) takes big/small distinct values on the first big points and one on the rest
@@ -229,17 +236,52 @@ __global__ __launch_bounds__(256) void k_pointwise_h_step(Fr *aA, const Fr *aB, 
 __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one(); }
 
 // Sparse witness upload: a credential's witness is ~97 % zeros and ones, so the host sends one tag byte per variable (0 zero, 1 one,
-// 2 listed) and the listed values as (index, value) records — 0.5 MB instead of 17.5 MB at 20 payloads.
-__global__ __launch_bounds__(256) void k_expand_tags(const uint8_t *tags, size_t n, Fr *z /* z[0] is the constant */) {
+// 2 listed) and the listed values as (index, value) records — 0.5 MB instead of 17.5 MB at 20 payloads.  The two kernels also ARE the
+// multi_exp_with_mixed_addition split of z = [1 | w] (what k_classify derives from a dense witness): k_expand_tags writes the constant,
+// the zeros and ones and their tags and clears the proof's counters, k_scatter_full writes the listed values, tags each by its VALUE (a
+// listed 0 or 1 is a bit like any other), lists the others and tells the host how many there are — the last workgroup to finish writes
+// into the pinned words, so no fill, classify or copy launch stands between the upload and the mat-vec.
+// words: [0] satisfiability flag, [1] k_r1cs_check's ticket, [2] k_scatter_full's ticket, [3] bad listed entry; count: [0] listed, [1] a listed element misses the witness tables
+__global__ __launch_bounds__(256) void k_expand_tags(const uint8_t *tags, size_t n, Fr *z /* z[0] is the constant */, uint8_t *wtags, uint32_t *words, uint32_t *count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { z[0] = Fr::one(); wtags[0] = 1; words[0] = 0; words[1] = 0; words[2] = 0; words[3] = 0; count[0] = 0; count[1] = 0; }
     if (i >= n) return;
-    z[i + 1] = tags[i] == 1 ? Fr::one() : Fr::zero();                          // listed entries are overwritten by k_scatter_full
+    const bool one = tags[i] == 1;
+    z[i + 1] = one ? Fr::one() : Fr::zero();                                   // listed entries are overwritten by k_scatter_full
+    wtags[i + 1] = one ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_scatter_full(const uint32_t *idx, const Fr *vals, size_t count, size_t n, Fr *z) {
+__global__ __launch_bounds__(256) void k_scatter_full(const uint32_t *idx, const Fr *vals, size_t cnt, size_t n, Fr *z, const uint8_t *tags, uint8_t *wtags,
+                                                      uint32_t *listed, uint32_t *count, uint32_t *words, const uint32_t *subset_pos, uint32_t *host_words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    uint32_t v = idx[i];
-    if (v < n) z[(size_t)v + 1] = vals[i];
+    uint32_t tag = 0, pos = 0;
+    if (i < cnt) {
+        const uint32_t v = idx[i];
+        if (v >= n || tags[v] != 2) or_and_wait(words + 3);                    // a listed index must be in range and tagged 2 (and listed once)
+        else {
+            const Fr val = vals[i];
+            uint32_t any = 0, diff = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { any |= val.v[j]; diff |= val.v[j] ^ FrParams::ONE[j]; }
+            tag = any == 0 ? 0u : (diff == 0 ? 1u : 2u);
+            pos = v + 1;
+            z[pos] = val; wtags[pos] = (uint8_t)tag;
+        }
+    }
+    const unsigned long long mask = __ballot(tag == 2);
+    if (mask) {
+        const uint32_t lane = threadIdx.x & 63, leader = (uint32_t)__ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (tag == 2) {
+            listed[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = pos;
+            if (subset_pos && subset_pos[pos] == SUBSET_NONE) or_and_wait(count + 1);    // the witness tables do not cover this element (yet)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(words + 2, 1u) == gridDim.x - 1) {
+        host_words[1] = atomicOr(count, 0u); host_words[2] = atomicOr(count + 1, 0u); host_words[3] = atomicOr(words + 3, 0u);
+    }
 }
 
 // H_tmp = (aA . aB - aC) * Zinv  (divide_by_Z_on_coset fused with the pointwise product)
@@ -286,9 +328,17 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
     hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
     Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
-    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
-    if (crs->n && W.dense) ZK_HIP(hipMemcpyAsync(z + 1, W.dense, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
-    if (crs->n && !W.dense) {
+    uint32_t *words = S.flag.as<uint32_t>(), *count = S.wcount.as<uint32_t>();
+    const uint32_t *subset_pos = crs->sub.count ? crs->sub.pos.as<uint32_t>() : nullptr;
+    if (W.dense || !crs->n) {
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, z);
+        if (crs->n) ZK_HIP(hipMemcpyAsync(z + 1, W.dense, (size_t)crs->n * 32, hipMemcpyHostToDevice, s));
+        ZK_HIP(hipMemsetAsync(words, 0, 16, s));
+        // the multi_exp_with_mixed_addition split of z: tags, the indices of the non-bit elements, and their count (read by the host)
+        // (and whether every one of them has its place in the witness tables: flag_host[2])
+        if (witness_classify(z, (size_t)crs->n + 1, S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), count, s, subset_pos)) return ZKG_ERROR;
+        ZK_HIP(hipMemcpyAsync(S.flag_host + 1, count, 8, hipMemcpyDeviceToHost, s));
+    } else {
         const size_t n = crs->n, cnt = W.count;
         if (S.up_tags.reserve(n) || S.up_idx.reserve(cnt * 4 + 16) || S.up_vals.reserve(cnt * 32 + 16)) return ZKG_ERROR;
         ZK_HIP(hipMemcpyAsync(S.up_tags.p, W.tags, n, hipMemcpyHostToDevice, s));
@@ -296,15 +346,10 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
             ZK_HIP(hipMemcpyAsync(S.up_idx.p, W.idx, cnt * 4, hipMemcpyHostToDevice, s));
             ZK_HIP(hipMemcpyAsync(S.up_vals.p, W.vals, cnt * 32, hipMemcpyHostToDevice, s));
         }
-        hipLaunchKernelGGL(k_expand_tags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S.up_tags.as<uint8_t>(), n, z);
-        if (cnt) hipLaunchKernelGGL(k_scatter_full, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, S.up_idx.as<uint32_t>(), S.up_vals.as<Fr>(), cnt, n, z);
+        hipLaunchKernelGGL(k_expand_tags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S.up_tags.as<uint8_t>(), n, z, S.wtags.as<uint8_t>(), words, count);
+        if (cnt) hipLaunchKernelGGL(k_scatter_full, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, S.up_idx.as<uint32_t>(), S.up_vals.as<Fr>(), cnt, n, z,
+                                    S.up_tags.as<uint8_t>(), S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), count, words, subset_pos, S.flag_host);
     }
-    ZK_HIP(hipMemsetAsync(S.flag.p, 0, 4, s));
-    // the multi_exp_with_mixed_addition split of z: tags, the indices of the non-bit elements, and their count (read by the host)
-    // (and whether every one of them has its place in the witness tables: flag_host[2])
-    if (witness_classify(z, (size_t)crs->n + 1, S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), S.wcount.as<uint32_t>(), s,
-                         crs->sub.count ? crs->sub.pos.as<uint32_t>() : nullptr)) return ZKG_ERROR;
-    ZK_HIP(hipMemcpyAsync(S.flag_host + 1, S.wcount.p, 8, hipMemcpyDeviceToHost, s));
     if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident and split from here on
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
@@ -317,8 +362,7 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
                            crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                            crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(), z, aA, aB, aC);
     if (want_flag) {
-        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, S.flag.as<uint32_t>());
-        ZK_HIP(hipMemcpyAsync(flag_out, S.flag.p, 4, hipMemcpyDeviceToHost, s));
+        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, words, flag_out);
         if (S.ev_ok) (void)hipEventRecord(S.ev[3], s);
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[1], s);
@@ -361,7 +405,7 @@ static int table_window_bits(size_t n) {                                    // w
 static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (S.ready) return ZKG_OK;
     const size_t n = crs->n, m = crs->m;
-    bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(4) == 0 && S.ntt_scratch.reserve(3 * m * NTT_SCRATCH_BYTES) == 0 &&
+    bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(16) == 0 && S.ntt_scratch.reserve(3 * m * NTT_SCRATCH_BYTES) == 0 &&
               S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(8) == 0 &&
               hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
     if (ok) {
@@ -748,7 +792,7 @@ static int h_shards_finish(zkg_crs *crs, ProverSlot &S, G1 &out) {
 static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness, const uint64_t r_[4], const uint64_t s_[4], bool check) {
     S.t0 = std::chrono::steady_clock::now();
     S.check = check; memcpy(S.r.v, r_, 32); memcpy(S.s.v, s_, 32);
-    S.flag_host[0] = 0; S.flag_host[1] = 0;
+    S.flag_host[0] = 0; S.flag_host[1] = 0; S.flag_host[2] = 0; S.flag_host[3] = 0;
     if (compute_h_matvec(crs, S, witness, check)) return ZKG_ERROR;
     lap(S, "upload + mat-vec enqueued");
     const size_t n = crs->n, l = crs->l, m = crs->m;
@@ -758,6 +802,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     auto witness_fn = [&]() -> int {
         ZK_HIP(hipEventSynchronize(S.ev[0]));
         const size_t listed = S.flag_host[1];
+        if (S.flag_host[3]) { set_error("prover: a listed witness index is out of range or not tagged 2"); return ZKG_ERROR; }
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
         const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
         if (listed && (S.flag_host[2] || !crs->sub.count)) {
@@ -852,6 +897,7 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     }
     // ---- finish + assembly (host), ordered so that nothing the GPU has already delivered waits for what it is still computing
     if (msm_job_finish(S.job_w1, W1, nullptr) || !hip_ok(hipStreamSynchronize(S.stream_o), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
+    lap(S, "A, B_1, L landed");
     for (int i = 0; i < 3; ++i) W1[i].add(S.ones_g1.g1(i));                   // bucket method over the non-bit elements + flat sum over the ones
     // the two variable-base products s W_a and r W_b: the second one on a helper thread
     G1 rWb;
@@ -864,11 +910,13 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     gC.add(rWb); gC.add(c_fixed); gC.add(W1[2]);
     lap(S, "A serialised, s*Wa + r*Wb + L");
     if (msm_job_finish(S.job_w2, nullptr, &Bt2) || !hip_ok(hipEventSynchronize(S.ev[10]), "sync", __FILE__, __LINE__)) { slot_drain(crs, S); return ZKG_ERROR; }
+    lap(S, "B_2 landed");
     Bt2.add(S.ones_g2.g2pt(0));
     gB2.add(Bt2);
     off += ser_g2(proof_out + off, gB2);
     lap(S, "B serialised");
     if (crs->h_shards.empty() ? msm_job_finish(S.job_h, &Ht, nullptr) : h_shards_finish(crs, S, Ht)) { slot_drain(crs, S); return ZKG_ERROR; }
+    lap(S, "H landed");
     gC.add(Ht);                                                             // C = H_t + L_t + s A + r B_1 - rs delta
     off += ser_g1(proof_out + off, gC);
     *proof_len = off;
