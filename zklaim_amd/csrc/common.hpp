@@ -127,6 +127,7 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = fals
 hipStream_t msm_job_stream(MsmJob *j);
 void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws);   // the job computes sum over windows w0, w0+ws, ... of 2^(cw) V_w only
 void msm_job_set_skewed(MsmJob *j, bool skewed);            // scalars known to be mostly equal (0/1 witness): use the one-pass sort directly
+void msm_job_set_row_merge(MsmJob *j, uint32_t f);        // table launches without a gather list: f consecutive windows share a row of buckets (1 = off)
 void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_destroy(MsmJob *j);
 // d_gather (optional, n entries): scalar i is d_scalars[d_gather[i]] and stands for element d_gather[i] of every base set

@@ -935,6 +935,10 @@ struct MsmJob {
     MsmGroup group[2];                 // [0] the G1 sets, [1] the G2 sets of the launch
     MsmGeom g{}; size_t n = 0;
     int window_hint = 0;               // 0: pick_geom's rule
+    // Table launches: every window's digit weighs the same, so f consecutive windows can share one row of buckets — a row is then a window
+    // over the f n entries (level, point) of its levels, which lie back to back in the table.  Same sorted list (rows of the digit array
+    // are simply read in pairs), W / f x B accumulators instead of W x B: the fold's additions shrink with it and chains get f times longer.
+    uint32_t merge_hint = 1, merge = 1;
     bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     bool empty = false;
@@ -1105,6 +1109,8 @@ static XYZZ<F> host_combine(const MsmJob *job, const MsmGroup &gr, int set) {
 }
 
 static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const uint32_t *d_gather) {
+    const MsmGeom g0 = job->g; const size_t n0 = job->n;                        // as the scalars see them (k_digits)
+    if (job->merge > 1) { job->g.W /= job->merge; job->g.Wt = job->g.W; job->n *= job->merge; }     // rows of the digit array read `merge` at a time from here on
     const MsmGeom g = job->g; const size_t n = job->n;
     hipStream_t s = job->stream;
     const size_t total = (size_t)g.W * g.B;
@@ -1137,7 +1143,7 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
             if (job->rx_meta.reserve((3 * (size_t)nbins + 8) * 4)) return ZKG_ERROR;
             zl.p[k] = job->rx_meta.as<uint32_t>(); zl.words[k++] = 3 * nbins + 8;
         }
-        hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_gather, n, (int)mont, g, digits, zl);   // n >= 1 (msm_job_launch)
+        hipLaunchKernelGGL(k_digits, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, d_scalars, d_gather, n0, (int)mont, g0, digits, zl);   // n >= 1 (msm_job_launch)
     }
     if (two_pass) {
         // two-pass sort: 2^cbits coarse bins per window, then the remaining fbits inside LDS
@@ -1178,6 +1184,7 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     return j;
 }
 void msm_job_set_window(MsmJob *j, int c) { if (j) j->window_hint = c; }
+void msm_job_set_row_merge(MsmJob *j, uint32_t f) { if (j) j->merge_hint = f ? f : 1; }
 void msm_job_set_skewed(MsmJob *j, bool skewed) { if (j) j->one_pass_sort = skewed; }
 void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws) { if (j) { j->w0 = w0; j->ws = ws ? ws : 1; } }
 hipStream_t msm_job_stream(MsmJob *j) { return j->stream; }
@@ -1210,7 +1217,16 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
     for (int i = 0; i < nsets; ++i) { MsmGroup &gr = job->group[sets[i].g2 ? 1 : 0]; by_field[sets[i].g2 ? 1 : 0][gr.nsets] = sets[i]; gr.out_index[gr.nsets] = gr.nsets; ++gr.nsets; }
     if (job->g.W == 0 || n == 0) { job->empty = true; return ZKG_OK; }        // no point, or this rank owns no window: the identity
     if ((uint64_t)n * job->g.W >= ((uint64_t)1 << 32)) { set_error("msm: n * windows exceeds the 32-bit index space of the sorted list (n < 2^28)"); return ZKG_ERROR; }
+    job->merge = 1;
+    if (any_table && job->merge_hint > 1 && !d_gather && job->g.W % job->merge_hint == 0 && (uint64_t)n * job->merge_hint < ((uint64_t)1 << 31)) {
+        bool ok = true;
+        for (int i = 0; i < nsets; ++i) ok = ok && sets[i].level_stride == n && sets[i].index_sub == 0 && !sets[i].remap;      // levels back to back, entry i = point i
+        if (ok) job->merge = job->merge_hint;
+    }
     if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return ZKG_ERROR;
+    if (job->merge > 1) {
+        for (int k = 0; k < 2; ++k) for (int i = 0; i < job->group[k].nsets; ++i) by_field[k][i].level_stride *= job->merge;
+    }
     lap("sort enqueued");
     const bool timed_field_g2 = job->group[0].nsets == 0;                       // the kernel timer follows the first G1 launch (G2 when there is no G1 set)
     if (job->group[1].nsets && launch_accumulate<Fq2>(job, job->group[1], by_field[1], d_gather, job == &g_default_job && timed_field_g2)) return ZKG_ERROR;   // G2 first: the longer chains
@@ -1220,7 +1236,11 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
 }
 // wait for the job's stream and finish on the host; outputs in launch order: out_g1[k] for the k-th G1 set, out_g2[k] for the k-th G2 set
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
+    static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     ZK_HIP(hipStreamSynchronize(job->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    struct Lap { bool on; std::chrono::steady_clock::time_point a, b; ~Lap() { if (on) fprintf(stderr, "[zkg]     job finish: waited %.3f ms, host combine %.3f ms\n", std::chrono::duration<float, std::milli>(b - a).count(), std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - b).count()); } } lap_{dbg, t0, t1};
     for (int k = 0; k < job->group[0].nsets; ++k) out_g1[k] = job->empty ? G1::inf() : host_combine<Fq>(job, job->group[0], k);
     for (int k = 0; k < job->group[1].nsets; ++k) out_g2[k] = job->empty ? G2::inf() : host_combine<Fq2>(job, job->group[1], k);
     return ZKG_OK;

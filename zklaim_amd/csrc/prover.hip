@@ -429,6 +429,9 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
              hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
             msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w); msm_job_set_window(S.job_h, crs->H_query.c);
+            // H: sixteen windows in eight rows of buckets from 2^17 points on (8 payloads: 1.22 -> 1.17 ms; four rows: 1.26 — one round of lanes,
+            // the longest chain sets the time; one payload, 2^15 points: 0.75 -> 0.89, the doubled rows leave the one-pass sort's range)
+            { static const int force = getenv("ZKG_H_ROW_MERGE") ? atoi(getenv("ZKG_H_ROW_MERGE")) : 0; msm_job_set_row_merge(S.job_h, force ? (uint32_t)force : (crs->H_query.n >= ((size_t)1 << 17) ? 2u : 1u)); }
         }
     }
     if (ok) {
@@ -757,7 +760,7 @@ static int h_shards_launch(zkg_crs *crs, ProverSlot &S) {
             ZK_HIP(hipSetDevice(run.device));
             run.job = msm_job_create(nullptr, true);
             if (!run.job || run.scalars.reserve(crs->h_shards[i].n * 32 + 16)) { set_error("prover: H shard workspace"); return ZKG_ERROR; }
-            msm_job_set_window(run.job, crs->h_shards[i].table.c);
+            msm_job_set_window(run.job, crs->h_shards[i].table.c); msm_job_set_row_merge(run.job, crs->h_shards[i].n >= ((size_t)1 << 17) ? 2u : 1u);
         }
         S.h_epoch = crs->h_epoch;
     }
