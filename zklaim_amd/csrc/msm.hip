@@ -939,6 +939,9 @@ struct MsmJob {
     // over the f n entries (level, point) of its levels, which lie back to back in the table.  Same sorted list (rows of the digit array
     // are simply read in pairs), W / f x B accumulators instead of W x B: the fold's additions shrink with it and chains get f times longer.
     uint32_t merge_hint = 1, merge = 1;
+    // a plain G1 set's conversion to 29-bit records (k_bases_to29) runs on a stream of its own beside the digit sort, whose small launches
+    // leave most of the chip idle: fork after everything queued before (the previous launch's accumulation still reads the records), join before the accumulation
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool converted_aside = false;
     bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     bool empty = false;
@@ -986,8 +989,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if constexpr (sizeof(F) == sizeof(Fq)) {
         if (ns == 1 && !accum32 && plain) {
             use29 = true;
-            if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
-            hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+            if (job->converted_aside) ZK_HIP(hipStreamWaitEvent(s, job->ev_join, 0));       // converted beside the sort (msm_job_launch)
+            else {
+                if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+                hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+            }
             rec29 = gr.bases29.as<Affine29>();
         } else if (ns == 1 && !accum32 && !d_gather && sets[0].p29 && !sets[0].remap && sets[0].index_sub == 0) {
             use29 = true; rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
@@ -1192,6 +1198,9 @@ void msm_job_destroy(MsmJob *j) {
     if (!j) return;
     for (DevBuf *b : {&j->digits, &j->hist, &j->counts, &j->offsets, &j->scan_sums, &j->class_hist, &j->order, &j->sorted, &j->rx_tmp, &j->rx_meta}) b->release();
     for (auto &gr : j->group) gr.release();
+    if (j->aux) { (void)hipStreamSynchronize(j->aux); (void)hipStreamDestroy(j->aux); }
+    if (j->ev_fork) (void)hipEventDestroy(j->ev_fork);
+    if (j->ev_join) (void)hipEventDestroy(j->ev_join);
     if (j->own_stream) (void)hipStreamDestroy(j->stream);
     delete j;
 }
@@ -1222,6 +1231,21 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
         bool ok = true;
         for (int i = 0; i < nsets; ++i) ok = ok && sets[i].level_stride == n && sets[i].index_sub == 0 && !sets[i].remap;      // levels back to back, entry i = point i
         if (ok) job->merge = job->merge_hint;
+    }
+    job->converted_aside = false;
+    {
+        static const bool accum32 = getenv("ZKG_ACCUM_32") != nullptr, inline29 = getenv("ZKG_TO29_INLINE") != nullptr;       // A/B switches
+        MsmGroup &g1 = job->group[0];
+        if (!accum32 && !inline29 && !any_table && !d_gather && g1.nsets == 1 && by_field[0][0].index_sub == 0 && !by_field[0][0].remap) {
+            if (!job->aux && (hipStreamCreateWithFlags(&job->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&job->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&job->ev_join, hipEventDisableTiming) != hipSuccess)) { set_error("msm: side stream"); return ZKG_ERROR; }
+            if (g1.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+            ZK_HIP(hipEventRecord(job->ev_fork, job->stream));
+            ZK_HIP(hipStreamWaitEvent(job->aux, job->ev_fork, 0));
+            hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, job->aux, reinterpret_cast<const Affine<Fq> *>(by_field[0][0].p), n, g1.bases29.as<Affine29>());
+            ZK_HIP(hipEventRecord(job->ev_join, job->aux));
+            job->converted_aside = true;
+        }
     }
     if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return ZKG_ERROR;
     if (job->merge > 1) {
@@ -1472,6 +1496,9 @@ void msm_release_all() {
     std::lock_guard<std::mutex> lk(j.mu);
     for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted, &j.rx_tmp, &j.rx_meta}) b->release();
     for (auto &gr : j.group) gr.release();
+    if (j.aux) { (void)hipStreamSynchronize(j.aux); (void)hipStreamDestroy(j.aux); j.aux = nullptr; }      // (a later zkg_init may pick another device)
+    if (j.ev_fork) { (void)hipEventDestroy(j.ev_fork); j.ev_fork = nullptr; }
+    if (j.ev_join) { (void)hipEventDestroy(j.ev_join); j.ev_join = nullptr; }
 }
 
 }  // namespace zk
