@@ -234,7 +234,7 @@ static constexpr uint32_t RX_MAX_CBITS = 10, RX_MAX_CB = 1u << RX_MAX_CBITS, RX_
 // temporary entry between the passes: fine bucket (fbits) in the top bits | point index << 1 | sign below.  cbits: log2 of the coarse bins
 // per window, chosen on the host so that a bin averages <= 4096 entries, half of what the second pass holds in LDS (measured: 1365 ...
 // 8192 all within 2 %).  The top window of a 254-bit scalar populates only 38 % of its buckets, so its bins are 2.65x as full and go to
-// k_rx_fine_big's plain path.
+// the streamed path of k_rx_fine (rx_fine_big_bin).
 __global__ __launch_bounds__(1024) void k_rx_count(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, uint32_t *cnt) {
     __shared__ uint32_t c[RX_MAX_CB];
     const uint32_t sl = blockIdx.x, w = blockIdx.y, t = threadIdx.x, CB = 1u << cbits;
@@ -325,51 +325,13 @@ ZK_D void rx_fine_offsets(uint32_t *cf, uint32_t *of, uint32_t FB, uint32_t t, u
     __syncthreads();
     for (uint32_t f = t; f < FB; f += 1024) { counts[gb0 + f] = cf[f]; offsets[gb0 + f] = start + of[f]; }
 }
-// second pass, one workgroup per (window, coarse bin) whose entries fit LDS (every bin of uniformly random scalars): entries stay in
-// registers between the count and the placement, the sorted bin is assembled in LDS and written out in order
-__global__ __launch_bounds__(1024) void k_rx_fine(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts, uint32_t *offsets,
-                                                   uint32_t *sorted) {
-    extern __shared__ uint32_t lds_u32[];
-    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
-    uint32_t *bufB = lds_u32, *cf = bufB + RX_FINE_MAX, *of = cf + FB, *cur = of + FB;       // 64 KiB + counters: two workgroups per CU
-    const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
-    const uint32_t start = base[bin], cnt = base[bin + 1] - start;
-    if (cnt > RX_FINE_MAX) return;                                    // k_rx_fine_big's
-    const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
-    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
-    __syncthreads();
-    uint32_t ent[RX_FINE_MAX / 1024];
-#pragma unroll
-    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
-        uint32_t p = t + j * 1024;
-        ent[j] = p < cnt ? tmp[start + p] : 0xffffffffu;
-        if (p < cnt) atomicAdd(&cf[ent[j] >> sh], 1u);
-    }
-    __syncthreads();
-    rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
-#pragma unroll
-    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
-        if (t + j * 1024 >= cnt) continue;
-        uint32_t e = ent[j], f = e >> sh;
-        bufB[of[f] + atomicAdd(&cur[f], 1u)] = e & low;
-    }
-    __syncthreads();
-    for (uint32_t p = t; p < cnt; p += 1024) sorted[start + p] = bufB[p];
-}
-// the bins k_rx_fine left: more entries than LDS holds, i.e. many equal digits (a 0/1 witness without ZKG_SCALARS_MOSTLY_BITS, adversarial
-// input).  One workgroup streams the bin twice; lanes of a wavefront that hold the same fine bucket share one LDS atomic and get
-// consecutive positions, so the stores of the dominant bucket are coalesced.
-__global__ __launch_bounds__(1024) void k_rx_fine_big(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts,
-                                                       uint32_t *offsets, uint32_t *sorted) {
-    extern __shared__ uint32_t lds_u32[];
-    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
-    uint32_t *cf = lds_u32, *of = cf + FB, *cur = of + FB;
-    const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
-    const uint32_t start = base[bin], cnt = base[bin + 1] - start;
-    if (cnt <= RX_FINE_MAX) return;
-    const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
-    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
-    __syncthreads();
+// A bin with more entries than LDS holds, i.e. many equal digits (a 0/1 witness without ZKG_SCALARS_MOSTLY_BITS, adversarial input, the
+// partly filled top window): the workgroup streams the bin twice; lanes of a wavefront that hold the same fine bucket share one LDS atomic
+// and get consecutive positions, so the stores of the dominant bucket are coalesced.  (Round 2 ran this as a kernel of its own: one
+// more launch per sort whose workgroups all returned at once for uniform scalars.)
+ZK_D void rx_fine_big_bin(const uint32_t *tmp, uint32_t fbits, uint32_t start, uint32_t cnt, size_t gb0, uint32_t *cf, uint32_t *of, uint32_t *cur, uint32_t *counts,
+                          uint32_t *offsets, uint32_t *sorted) {
+    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1, t = threadIdx.x;
     const bool giant = cnt > 8 * RX_FINE_MAX;                         // many equal digits; below that (a dense top window) plain atomics are faster
     if (!giant) {
         for (uint32_t p = t; p < cnt; p += 1024) atomicAdd(&cf[tmp[start + p] >> sh], 1u);
@@ -399,6 +361,37 @@ __global__ __launch_bounds__(1024) void k_rx_fine_big(const uint32_t *tmp, uint3
             if (live && f == lf) { sorted[start + of[lf] + basepos + (uint32_t)__popcll(below)] = e & low; live = false; }
         }
     }
+}
+// second pass, one workgroup per (window, coarse bin).  A bin whose entries fit LDS (every bin of uniformly random scalars): entries stay in
+// registers between the count and the placement, the sorted bin is assembled in LDS and written out in order
+__global__ __launch_bounds__(1024) void k_rx_fine(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts, uint32_t *offsets,
+                                                   uint32_t *sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
+    uint32_t *bufB = lds_u32, *cf = bufB + RX_FINE_MAX, *of = cf + FB, *cur = of + FB;       // 64 KiB + counters: two workgroups per CU
+    const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
+    const uint32_t start = base[bin], cnt = base[bin + 1] - start;
+    const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
+    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
+    __syncthreads();
+    if (cnt > RX_FINE_MAX) { rx_fine_big_bin(tmp, fbits, start, cnt, gb0, cf, of, cur, counts, offsets, sorted); return; }     // (uniform across the workgroup)
+    uint32_t ent[RX_FINE_MAX / 1024];
+#pragma unroll
+    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
+        uint32_t p = t + j * 1024;
+        ent[j] = p < cnt ? tmp[start + p] : 0xffffffffu;
+        if (p < cnt) atomicAdd(&cf[ent[j] >> sh], 1u);
+    }
+    __syncthreads();
+    rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
+#pragma unroll
+    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
+        if (t + j * 1024 >= cnt) continue;
+        uint32_t e = ent[j], f = e >> sh;
+        bufB[of[f] + atomicAdd(&cur[f], 1u)] = e & low;
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < cnt; p += 1024) sorted[start + p] = bufB[p];
 }
 
 // Heavy threshold, computed on the device from the real list lengths: a lane walks its bucket's list alone (~7 us per G1
@@ -1160,8 +1153,6 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
         hipLaunchKernelGGL(k_rx_scan, dim3(1), dim3(1024), 0, s, cnt, nbins, base, cursor, offsets + total);
         hipLaunchKernelGGL(k_rx_scatter, dim3(S1, g.W), dim3(1024), (RX_SLICE + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
         hipLaunchKernelGGL(k_rx_fine, dim3(CB, g.W), dim3(1024), (RX_FINE_MAX + 3 * (1u << fbits)) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
-                           job->sorted.as<uint32_t>());
-        hipLaunchKernelGGL(k_rx_fine_big, dim3(CB, g.W), dim3(1024), 3 * (1u << fbits) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
                            job->sorted.as<uint32_t>());
     } else {                                                                                    // one pass: histogram, scans, k_place
     hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist);
