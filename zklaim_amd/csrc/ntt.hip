@@ -377,7 +377,8 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
         A.n_log = n; A.s0 = s0; A.R = R;
         A.src_batch_stride = A.dst_batch_stride = batch_stride ? batch_stride : N;     // vectors and their scratch share one layout
         unsigned cols_log = n - R;                                   // columns in total
-        A.cw_log = cols_log < (unsigned)(NTT_TILE_LOG - R) ? cols_log : (unsigned)(NTT_TILE_LOG - R);
+        const unsigned room = (unsigned)NTT_TILE_LOG > R ? (unsigned)NTT_TILE_LOG - R : 0u;   // (a forced tile smaller than 2^R rows: one column per tile)
+        A.cw_log = cols_log < room ? cols_log : room;
         if (npass == 1) A.cw_log = 0;
         size_t tiles = (N >> R) >> A.cw_log;
         size_t rows = (size_t)1 << R, CW = (size_t)1 << A.cw_log;
