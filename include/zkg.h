@@ -202,7 +202,10 @@ int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_
                       const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* The same proof from a sparse description of the witness: tags[n] (0 = zero, 1 = one, 2 = listed) and `count` listed variables
  * as (index in 0..n-1, value as 4 Montgomery limbs).  For witness generators that know their bits (zkg_circuit_sparse_witness): the
- * host-to-device upload shrinks ~30x.  Proof bytes are identical to zkg_groth16_prove on the expanded vector. */
+ * host-to-device upload shrinks ~30x.  Proof bytes are identical to zkg_groth16_prove on the expanded vector.
+ * Every listed index must be in range, tagged 2 and listed once (a listed VALUE may be anything, 0 and 1 included); a tag-2 variable that
+ * is not listed counts as zero.  An index out of range or not tagged 2 is ZKG_ERROR; a repeated index is not detected (the proof is then
+ * that of an unspecified one of the repeated values — never an out-of-bounds access). */
 int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
                              const uint64_t r[4], const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */

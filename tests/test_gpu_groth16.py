@@ -190,6 +190,42 @@ def test_prove_sparse_witness_matches_dense(zkg):
     crs.free(); kp.free()
 
 
+def test_sparse_witness_upload_is_the_witness_split(zkg, oracle):
+    """The sparse upload builds z = [1 | w] AND its multi_exp_with_mixed_addition split in one go (k_expand_tags, k_scatter_full): a listed
+    value is tagged by what it IS (0 and 1 included), a tag-2 variable nobody lists is zero, a listed index that is out of range or not
+    tagged 2 is refused.  Proof bytes: the dense call's and the oracle's."""
+    vals_int = [0, 1, 5, R - 1, 1, 0, 7, 2, 1, 0, 123456789, 3]
+    n, l, A, B, C, w = _trivial_system(vals_int)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x5CA))
+    rs = random_fr_canonical(2, 0x5CB)
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0], rs[1])
+    log_m = crs_arrays["m"].bit_length() - 1
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, log_m, keep))
+    rc, dense = crs.prove(w, rs[0], rs[1])
+    assert rc_o == 0 and rc == 0 and dense == proof_o
+    # every variable listed (tag 2), whatever its value: the zeros and ones among them must land in the right part of the split
+    tags = np.full(n, 2, np.uint8); idx = np.arange(n, dtype=np.uint32)
+    assert crs.prove_sparse(tags, idx, w, rs[0], rs[1]) == (0, dense)
+    # bits by tag, the rest listed in reverse order
+    tags = np.array([0 if v == 0 else 1 if v == 1 else 2 for v in vals_int], np.uint8)
+    idx = np.flatnonzero(tags == 2)[::-1].astype(np.uint32)
+    assert crs.prove_sparse(tags, idx, w[idx], rs[0], rs[1]) == (0, dense)
+    # a tag-2 variable that is not listed counts as zero: the proof of the witness with that variable zeroed
+    w0 = w.copy(); w0[int(idx[0])] = 0
+    rc_z, proof_z = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w0, rs[0], rs[1])
+    assert rc_z == 0 and crs.prove_sparse(tags, idx[1:], w[idx[1:]], rs[0], rs[1]) == (0, proof_z)
+    # refused: an index out of range; an index whose tag is not 2
+    with pytest.raises(zkg.ZkgError):
+        crs.prove_sparse(tags, np.append(idx, np.uint32(n)), np.vstack([w[idx], w[:1]]), rs[0], rs[1])
+    bit = np.uint32(np.flatnonzero(tags == 1)[0])
+    with pytest.raises(zkg.ZkgError):
+        crs.prove_sparse(tags, np.append(idx, bit), np.vstack([w[idx], w[bit:bit + 1]]), rs[0], rs[1])
+    assert crs.prove_sparse(tags, idx, w[idx], rs[0], rs[1]) == (0, dense)            # the slot is clean afterwards
+    crs.free()
+
+
 def _trivial_system(values):
     """x_i * 1 = x_i for every variable: satisfied by ANY assignment, so the witness can be shaped at will (one public input)"""
     n = len(values)
