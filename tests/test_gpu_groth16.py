@@ -29,9 +29,10 @@ def test_prove_golden(zkg, case):
     crs.free()
 
 
-@pytest.mark.parametrize("log_m", [10, 13])
+@pytest.mark.parametrize("log_m", [10, 13, 16])
 def test_prove_zklaim_shaped_vs_oracle(zkg, oracle, log_m):
-    """Synthetic zklaim-shaped system (bits, AND/XOR, packing rows), CRS from the oracle's known-trapdoor generator."""
+    """Synthetic zklaim-shaped system (bits, AND/XOR, packing rows), CRS from the oracle's known-trapdoor generator.  2^16: the H query's
+    65535 points take the two-pass digit sort and windows that share rows of buckets in pairs (prover.hip H_ROW_MERGE_MIN)."""
     from zklaim_amd import synth
     n, l, A, B, C, w = synth.zklaim_shaped(log_m, num_inputs=5, seed=log_m)
     keep = []

@@ -398,6 +398,7 @@ static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
     return ZKG_OK;
 }
 
+static constexpr size_t H_ROW_MERGE_MIN = 49152;                               // points from which H's windows share rows of buckets in pairs (slot_create)
 static int table_window_bits(size_t n) {                                    // window size of a query's table, by the size of the query
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     return lg >= 15 ? 16 : lg >= 9 ? 12 : 8;
@@ -429,9 +430,10 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
              hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
             msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w); msm_job_set_window(S.job_h, crs->H_query.c);
-            // H: sixteen windows in eight rows of buckets from 2^17 points on (8 payloads: 1.22 -> 1.17 ms; four rows: 1.26 — one round of lanes,
-            // the longest chain sets the time; one payload, 2^15 points: 0.75 -> 0.89, the doubled rows leave the one-pass sort's range)
-            { static const int force = getenv("ZKG_H_ROW_MERGE") ? atoi(getenv("ZKG_H_ROW_MERGE")) : 0; msm_job_set_row_merge(S.job_h, force ? (uint32_t)force : (crs->H_query.n >= ((size_t)1 << 17) ? 2u : 1u)); }
+            // H: sixteen windows in eight rows of buckets from 49152 points on — where the unmerged launch already takes the two-pass sort
+            // (2 / 4 / 8 payloads: 0.78 -> 0.72, 0.93 -> 0.88, 1.22 -> 1.17 ms; four rows at 8 payloads: 1.26 — one round of lanes, the
+            // longest chain sets the time; one payload, 2^15 points: 0.75 -> 0.89, the doubled rows leave the one-pass sort's range)
+            { static const int force = getenv("ZKG_H_ROW_MERGE") ? atoi(getenv("ZKG_H_ROW_MERGE")) : 0; msm_job_set_row_merge(S.job_h, force ? (uint32_t)force : (crs->H_query.n >= H_ROW_MERGE_MIN ? 2u : 1u)); }
         }
     }
     if (ok) {
@@ -760,7 +762,7 @@ static int h_shards_launch(zkg_crs *crs, ProverSlot &S) {
             ZK_HIP(hipSetDevice(run.device));
             run.job = msm_job_create(nullptr, true);
             if (!run.job || run.scalars.reserve(crs->h_shards[i].n * 32 + 16)) { set_error("prover: H shard workspace"); return ZKG_ERROR; }
-            msm_job_set_window(run.job, crs->h_shards[i].table.c); msm_job_set_row_merge(run.job, crs->h_shards[i].n >= ((size_t)1 << 17) ? 2u : 1u);
+            msm_job_set_window(run.job, crs->h_shards[i].table.c); msm_job_set_row_merge(run.job, crs->h_shards[i].n >= H_ROW_MERGE_MIN ? 2u : 1u);
         }
         S.h_epoch = crs->h_epoch;
     }
@@ -835,6 +837,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
             ZK_HIP(hipStreamWaitEvent(S.stream_o, go, 0));
             if (ones_sum_launch(S.ones_g2, &o2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
             (void)hipEventRecord(S.ev[10], S.stream_o);                        // the G2 sum has landed (the G1 sums follow on the same stream)
+            if (g_serial_msm) (void)hipStreamSynchronize(S.stream_o);          // (profiling aid: the flat sum alone on the chip, then the job's kernels)
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[6], js);
             if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
@@ -844,6 +847,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
         {
             hipStream_t js = msm_job_stream(S.job_w1);
             if (ones_sum_launch(S.ones_g1, o1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            if (g_serial_msm) (void)hipStreamSynchronize(S.stream_o);
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[4], js);
             if (msm_job_launch(S.job_w1, g1, 3, z, listed, true, gather)) return ZKG_ERROR;
