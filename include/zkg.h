@@ -133,6 +133,17 @@ int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
                    uint64_t out_jac[12], void *stream);
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
                    uint64_t out_jac[24], void *stream);
+/* Fixed bases kept resident WITH their per-window tables (level w = 2^(c w) P_i; c = 16 from 2^15 points on: 16 x the bases' memory plus the
+ * same again as 29-bit records) — what the prover builds for a key's H query, offered for any fixed G1 base set (libff has no counterpart; its
+ * multi_exp takes the bases as they are).  Every window's digit then weighs the same: one bucket set, one reduction, no doublings on the
+ * host.  zkg_msm_g1_bases_upload reads n affine points from DEVICE memory (the layout zkg_msm_g1_dev takes) and builds the tables once;
+ * zkg_msm_g1_resident computes sum scalars[i] * P_i for n DEVICE scalars (n = the handle's point count) — the same point as
+ * zkg_msm_g1_dev, bit for bit.  Calls on one handle take turns.  bench.py reports it as a SECOND figure (extras.msm_resident_tables);
+ * the headline stays the plain path.                                                                                                  */
+typedef struct zkg_msm_bases zkg_msm_bases;
+zkg_msm_bases *zkg_msm_g1_bases_upload(const void *d_bases, size_t n);
+int zkg_msm_g1_resident(zkg_msm_bases *bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12]);
+void zkg_msm_g1_bases_free(zkg_msm_bases *bases);
 /* Window-sharded variant for multi-GPU runs where every GPU holds every base: the partial
  * sum over the Pippenger windows first_window, first_window + window_stride, ... only, each
  * already weighted by 2^(c w) — the partials of ranks g = 0..G-1 (first_window = g,

@@ -210,3 +210,34 @@ def test_multi_device_shards_in_one_process(zkg, oracle, n, devices):
         assert np.array_equal(parts[i], oracle.msm_g1(bases[lo:hi], sc[lo:hi]) if hi > lo else g1_jac_expected(None))
     assert np.array_equal(sh.msm(sc), got)                              # workspaces are reused across calls
     sh.free()
+
+
+@pytest.mark.parametrize("n", [1, 300, 5000, 70000])
+def test_resident_bases_with_window_tables_equal_the_plain_msm(zkg, oracle, n):
+    """zkg_msm_g1_bases_upload / zkg_msm_g1_resident (per-window tables of fixed bases: one bucket set, one reduction, no host doublings;
+    from 49152 points on also windows sharing rows of buckets): the same point as zkg_msm_g1_dev and the oracle, bit for bit — uniform
+    scalars, then mostly-bit scalars with r - 1, a duplicated base and a base at infinity; two calls on one handle; a wrong n is refused."""
+    import torch
+    d_bases, bases, _ = dev_bases_g1(zkg, n, 0xBA5E5 + n)
+    if n >= 300:
+        bases[7] = bases[8]; bases[9] = 0                               # a duplicated base, a base at infinity
+        d_bases = torch.from_numpy(bases.view(np.int64)).cuda()
+    h = zkg.ResidentBases(d_bases.data_ptr(), n)
+    sc = random_fr_canonical(n, 0xBA5E6 + n)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    got = h.msm(d_sc.data_ptr())
+    assert np.array_equal(got, zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n))
+    if n <= 5000:
+        assert np.array_equal(got, oracle.msm_g1(bases, sc))
+    sc2 = sc.copy(); rng = np.random.default_rng(n); kind = rng.integers(0, 100, n)
+    sc2[kind < 45] = 0; sc2[(kind >= 45) & (kind < 90), :] = np.array([1, 0, 0, 0], np.uint64); sc2[0] = limbs(R - 1)
+    if n >= 300:
+        sc2[7] = sc2[8] = limbs(R - 1)
+    d_sc2 = torch.from_numpy(sc2.view(np.int64)).cuda()
+    assert np.array_equal(h.msm(d_sc2.data_ptr()), zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n))
+    assert np.array_equal(h.msm(d_sc.data_ptr()), got)                 # the handle's job and tables are reusable
+    h.n = n + 1
+    with pytest.raises(zkg.ZkgError):
+        h.msm(d_sc.data_ptr())
+    h.n = n
+    h.free()

@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = [
     "zkg_circuit_is_satisfied", "zkg_circuit_first_unsatisfied", "zkg_zklaim_input_map", "zkg_groth16_setup", "zkg_keypair_free",
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
-    "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h",
+    "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h", "zkg_msm_g1_bases_upload", "zkg_msm_g1_resident", "zkg_msm_g1_bases_free",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -226,6 +226,29 @@ def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0, mostly_bits=
     flags = (SCALARS_MONT if scalars_mont else 0) | (SCALARS_MOSTLY_BITS if mostly_bits else 0)
     _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), flags, _p(out), _vp(stream)), "zkg_msm_g1_dev")
     return out
+
+
+class ResidentBases:
+    """zkg_msm_g1_bases_upload / zkg_msm_g1_resident: fixed G1 bases (device pointer, n affine points) kept with their per-window tables"""
+
+    def __init__(self, d_bases, n):
+        lib().zkg_msm_g1_bases_upload.restype = C.c_void_p
+        lib().zkg_msm_g1_bases_upload.argtypes = [C.c_void_p, C.c_size_t]
+        self._h = lib().zkg_msm_g1_bases_upload(_vp(d_bases), C.c_size_t(n))
+        if not self._h:
+            raise ZkgError("zkg_msm_g1_bases_upload failed: " + last_error())
+        self.n = n
+
+    def msm(self, d_scalars, scalars_mont=False):
+        out = np.zeros(12, np.uint64)
+        lib().zkg_msm_g1_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _check(lib().zkg_msm_g1_resident(C.c_void_p(self._h), _vp(d_scalars), C.c_size_t(self.n), SCALARS_MONT if scalars_mont else 0, _p(out)), "zkg_msm_g1_resident")
+        return out
+
+    def free(self):
+        if self._h:
+            lib().zkg_msm_g1_bases_free.argtypes = [C.c_void_p]
+            lib().zkg_msm_g1_bases_free(C.c_void_p(self._h)); self._h = None
 
 
 def msm_g1_windows_dev(d_bases, d_scalars, n, first_window, window_stride, scalars_mont=False, stream=0):

@@ -121,6 +121,7 @@ struct OwnedCsr { std::vector<uint32_t> rp[3], col[3]; std::vector<uint64_t> val
 struct WindowTable { DevBuf buf, rec29; size_t n = 0; int c = 0, W = 0; bool g2 = false; void release() { buf.release(); rec29.release(); n = 0; } };
 int window_table_records29(WindowTable &t, hipStream_t s);                // rec29 <- every level of a built G1 table as 29-bit records
 int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int c, hipStream_t s);
+int table_window_bits(size_t n);                          // window size of a query's table, by the size of the query (prover.hip)
 int window_table_build_g2(WindowTable &t, const G2Affine *d_bases, size_t n, int c, hipStream_t s);
 struct MsmJob;                                             // one MSM in flight: stream, workspace, pinned landing zone
 MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority = false);

@@ -399,7 +399,7 @@ static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
 }
 
 static constexpr size_t H_ROW_MERGE_MIN = 49152;                               // points from which H's windows share rows of buckets in pairs (slot_create)
-static int table_window_bits(size_t n) {                                    // window size of a query's table, by the size of the query
+int table_window_bits(size_t n) {                                    // window size of a query's table, by the size of the query
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     // (re-measured in round 3 with the 29-bit kernels, tools/ch_sweep.sh + tools/prove_throughput.py: one payload, 2^15 - 1 points: c = 12 / 13 / 15 / 16
     //  -> 0.75 / 0.71 / 0.67 / 0.71 ms for a lone caller but 1907 / 1874 / 1632 / 1539 proofs/s with three callers, and no difference through
