@@ -417,6 +417,26 @@ def test_concurrent_callers_get_the_serial_proofs(zkg, oracle):
         crs.free()
 
 
+def test_h_shards_large_enough_to_merge_window_rows(zkg, oracle):
+    """2^17 constraints over two shards: 65535 points each, so every shard's launch takes the two-pass sort and pairs its windows' rows of
+    buckets (prover.hip H_ROW_MERGE_MIN) — sharding and row merging together, against the unsharded key and the oracle"""
+    from zklaim_amd import synth
+    log_m = 17
+    n, l, A, B, C, w = synth.zklaim_shaped(log_m, num_inputs=5, seed=171)
+    keep = []
+    ocs = oracle.make_r1cs(n, l, A, B, C, keep)
+    crs_arrays = oracle.groth16_setup(ocs, random_fr_canonical(5, 0x5A4B4C41494D0171))
+    rs = random_fr_canonical(2, 0x5A4B4C41494D0172)
+    rc_o, proof_o = oracle.groth16_prove(oracle.make_pk(ocs, crs_arrays), w, rs[0], rs[1])
+    crs = zkg.Crs(zkg.make_pk(zkg.make_r1cs(n, l, A, B, C, keep), crs_arrays, log_m, keep))
+    assert rc_o == 0 and crs.prove(w, rs[0], rs[1]) == (0, proof_o)
+    crs.shard_h([0, 0])
+    assert crs.prove(w, rs[0], rs[1]) == (0, proof_o)
+    crs.shard_h([0, 0, 0])                                           # 43690 points each: below the merge threshold again
+    assert crs.prove(w, rs[0], rs[1]) == (0, proof_o)
+    crs.free()
+
+
 @pytest.mark.parametrize("shards", [[0, 0], [0, 0, 0], [0] * 8], ids=["2", "3", "8"])
 def test_one_proof_with_the_h_query_sharded(zkg, oracle, shards):
     """SURVEY §8(e), one proof over several devices from C: zkg_crs_shard_h splits the H query by points (a device listed several times
