@@ -442,7 +442,7 @@ def main():
         "metric": "Groth16 proofs/sec (zklaim gadget, alt_bn128) + G1 MSM GB/s vs HBM roofline", "metric_component": "G1 MSM GB/s (value, unit); Groth16 proofs/sec of the zklaim gadget in extras.groth16_prove and proofs_per_sec", "value": round(value, 3), "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_stats": stats_ms(per_step),
         "incl_scalar_h2d": h2d, "all_ranks_same_result": same_everywhere, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8-montgomery (254-bit Fq/Fr)", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs, Montgomery (254-bit Fq/Fr: 9 x 29-bit in the accumulation, reduction and NTT kernels, 8 x 32-bit elsewhere)", "data": "synthetic",
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
                    "sharding": ("windows sharded per rank (every rank holds all points); " if by_windows else "points sharded per rank; ") + "all-gather of normalised partial points + EC add" if world > 1 else "single GPU"},
