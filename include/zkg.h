@@ -138,11 +138,13 @@ int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
  * multi_exp takes the bases as they are).  Every window's digit then weighs the same: one bucket set, one reduction, no doublings on the
  * host.  zkg_msm_g1_bases_upload reads n affine points from DEVICE memory (the layout zkg_msm_g1_dev takes) and builds the tables once;
  * zkg_msm_g1_resident computes sum scalars[i] * P_i for n DEVICE scalars (n = the handle's point count) — the same point as
- * zkg_msm_g1_dev, bit for bit.  Calls on one handle take turns.  bench.py reports it as a SECOND figure (extras.msm_resident_tables);
- * the headline stays the plain path.                                                                                                  */
+ * zkg_msm_g1_dev, bit for bit.  Calls on one handle take turns.  Ordering: the job runs on a stream of the handle's own, behind everything
+ * queued on `stream` (NULL: the null stream) at the time of the call — the work that wrote d_scalars — and the call returns when the result
+ * is in out_jac.  The calling thread's current device must be the one the handle was made on (otherwise ZKG_ERROR); zkg_msm_g1_bases_free
+ * may be called from any device.  bench.py reports it as a SECOND figure (extras.msm_resident_tables); the headline stays the plain path.                                                                                                  */
 typedef struct zkg_msm_bases zkg_msm_bases;
 zkg_msm_bases *zkg_msm_g1_bases_upload(const void *d_bases, size_t n);
-int zkg_msm_g1_resident(zkg_msm_bases *bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12]);
+int zkg_msm_g1_resident(zkg_msm_bases *bases, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream);
 void zkg_msm_g1_bases_free(zkg_msm_bases *bases);
 /* Window-sharded variant for multi-GPU runs where every GPU holds every base: the partial
  * sum over the Pippenger windows first_window, first_window + window_stride, ... only, each
@@ -215,8 +217,8 @@ int zkg_groth16_prove(const zkg_crs *crs, const uint64_t *witness, const uint64_
  * as (index in 0..n-1, value as 4 Montgomery limbs).  For witness generators that know their bits (zkg_circuit_sparse_witness): the
  * host-to-device upload shrinks ~30x.  Proof bytes are identical to zkg_groth16_prove on the expanded vector.
  * Every listed index must be in range, tagged 2 and listed once (a listed VALUE may be anything, 0 and 1 included); a tag-2 variable that
- * is not listed counts as zero.  An index out of range or not tagged 2 is ZKG_ERROR; a repeated index is not detected (the proof is then
- * that of an unspecified one of the repeated values — never an out-of-bounds access). */
+ * is not listed counts as zero.  An index out of range, not tagged 2 or listed twice is ZKG_ERROR (detected on the device: each listed
+ * variable's tag byte is claimed once; no proof is written). */
 int zkg_groth16_prove_sparse(const zkg_crs *crs, const uint8_t *tags, const uint32_t *full_index, const uint64_t *full_values, size_t count,
                              const uint64_t r[4], const uint64_t s[4], int check_satisfied, uint8_t *proof_out, size_t *proof_len);
 /* coefficients_for_H (m+1 Fr, Montgomery) of r1cs_to_qap_witness_map, for parity tests */
@@ -226,6 +228,10 @@ int zkg_qap_witness_h(const zkg_crs *crs, const uint64_t *witness, uint64_t *h_o
  * elements (one batched job), [3] unused, [4] B(G2) over the same elements, [5] H, [6] unused, [7] wall-clock total incl. host
  * assembly.  The flat sums over the witness elements equal to one run beside [2] and [4] on a stream of their own.               */
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]);
+/* the largest number of proofs one resident key has had in flight at once (callers on several threads share a key's prover slots: up
+ * to three below m = 2^18, two at 2^18, one above) since the last call with reset != 0.  A counter, not a clock: what the concurrency
+ * tests assert instead of wall-clock ratios. */
+int zkg_prover_peak_in_flight(int reset);
 
 /* ---- zklaim's credential circuit on the host: replaces protoboard + zklaim_gadget construction,
  *      generate_r1cs_constraints and generate_r1cs_witness (snark.cpp:113-118, zklaim_gadget.cpp:153-784) and

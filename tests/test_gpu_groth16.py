@@ -223,6 +223,14 @@ def test_sparse_witness_upload_is_the_witness_split(zkg, oracle):
     bit = np.uint32(np.flatnonzero(tags == 1)[0])
     with pytest.raises(zkg.ZkgError):
         crs.prove_sparse(tags, np.append(idx, bit), np.vstack([w[idx], w[bit:bit + 1]]), rs[0], rs[1])
+    # refused: an index listed twice — with the same value or another one (it used to count z[i] twice in A / B / L and once in H: ZKG_OK
+    # with a proof that does not verify); adjacent in one wavefront and far apart
+    for dup_at in (0, len(idx) - 1):
+        d = idx[dup_at:dup_at + 1]
+        with pytest.raises(zkg.ZkgError):
+            crs.prove_sparse(tags, np.append(idx, d), np.vstack([w[idx], w[d]]), rs[0], rs[1])
+        with pytest.raises(zkg.ZkgError):
+            crs.prove_sparse(tags, np.append(d, idx), np.vstack([w[:1], w[idx]]), rs[0], rs[1])
     assert crs.prove_sparse(tags, idx, w[idx], rs[0], rs[1]) == (0, dense)            # the slot is clean afterwards
     crs.free()
 

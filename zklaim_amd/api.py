@@ -22,6 +22,7 @@ DECLARED_SYMBOLS = [
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
     "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h", "zkg_msm_g1_bases_upload", "zkg_msm_g1_resident", "zkg_msm_g1_bases_free",
+    "zkg_prover_peak_in_flight",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -239,10 +240,11 @@ class ResidentBases:
             raise ZkgError("zkg_msm_g1_bases_upload failed: " + last_error())
         self.n = n
 
-    def msm(self, d_scalars, scalars_mont=False):
+    def msm(self, d_scalars, scalars_mont=False, stream=0):
+        """`stream`: the HIP stream whose queued work produced d_scalars (0 = the null stream); the job is ordered behind it"""
         out = np.zeros(12, np.uint64)
-        lib().zkg_msm_g1_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-        _check(lib().zkg_msm_g1_resident(C.c_void_p(self._h), _vp(d_scalars), C.c_size_t(self.n), SCALARS_MONT if scalars_mont else 0, _p(out)), "zkg_msm_g1_resident")
+        lib().zkg_msm_g1_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        _check(lib().zkg_msm_g1_resident(C.c_void_p(self._h), _vp(d_scalars), C.c_size_t(self.n), SCALARS_MONT if scalars_mont else 0, _p(out), _vp(stream)), "zkg_msm_g1_resident")
         return out
 
     def free(self):

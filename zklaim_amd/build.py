@@ -25,13 +25,19 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # shared inputs (headers, generated streams, the C ABI): a change there recompiles everything; otherwise only the sources that changed
+    shared = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if not f.endswith(".hip")] + \
+             [os.path.join(HERE, "..", "include", f) for f in ("zkg.h", "zklaim_abi.h")] + [os.path.abspath(__file__)]
+    shared_t = max(os.path.getmtime(f) for f in shared)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(shared_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")

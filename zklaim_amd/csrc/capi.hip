@@ -336,7 +336,7 @@ int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n,
     return ZKG_OK;
 }
 // ---- fixed bases kept resident with their per-window tables (what the prover's H query gets): include/zkg.h
-struct zkg_msm_bases { WindowTable table; MsmJob *job = nullptr; std::mutex mu; int device = 0; };
+struct zkg_msm_bases { WindowTable table; MsmJob *job = nullptr; std::mutex mu; int device = 0; hipEvent_t ev_in = nullptr; };
 zkg_msm_bases *zkg_msm_g1_bases_upload(const void *d_bases, size_t n) {
     if (g_device < 0) { set_error("zkg_init not called"); return nullptr; }
     if (!d_bases || n == 0 || n >= ((size_t)1 << 27)) { set_error("zkg_msm_g1_bases_upload: bad argument"); return nullptr; }
@@ -344,7 +344,7 @@ zkg_msm_bases *zkg_msm_g1_bases_upload(const void *d_bases, size_t n) {
     if (!h) return nullptr;
     (void)hipGetDevice(&h->device);
     h->job = msm_job_create(nullptr, true);
-    bool ok = h->job != nullptr && window_table_build_g1(h->table, (const G1Affine *)d_bases, n, table_window_bits(n), nullptr) == 0 && window_table_records29(h->table, nullptr) == 0 &&
+    bool ok = h->job != nullptr && hip_ok(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming), "hipEventCreate", __FILE__, __LINE__) && window_table_build_g1(h->table, (const G1Affine *)d_bases, n, table_window_bits(n), nullptr) == 0 && window_table_records29(h->table, nullptr) == 0 &&
               hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
     if (!ok) { zkg_msm_g1_bases_free(h); return nullptr; }
     msm_job_set_window(h->job, h->table.c); msm_job_set_row_merge(h->job, n >= 49152 ? 2u : 1u);
@@ -352,14 +352,24 @@ zkg_msm_bases *zkg_msm_g1_bases_upload(const void *d_bases, size_t n) {
 }
 void zkg_msm_g1_bases_free(zkg_msm_bases *h) {
     if (!h) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    if (cur != h->device) (void)hipSetDevice(h->device);               // the handle's memory, stream and event live on the device it was made on
     if (h->job) { (void)hipStreamSynchronize(msm_job_stream(h->job)); msm_job_destroy(h->job); }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     h->table.release();
+    if (cur != h->device) (void)hipSetDevice(cur);
     delete h;
 }
-int zkg_msm_g1_resident(zkg_msm_bases *h, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12]) {
+int zkg_msm_g1_resident(zkg_msm_bases *h, const void *d_scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
     REQUIRE_INIT();
     if (!h || !d_scalars || !out_jac || n != h->table.n) { set_error("zkg_msm_g1_resident: bad argument (n must be the handle's point count)"); return ZKG_ERROR; }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) { set_error("zkg_msm_g1_resident: the calling thread's device is not the one the bases were uploaded on"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(h->mu);                              // the handle owns one job: calls take turns
+    // the job runs on the handle's own (non-blocking) stream: order it behind whatever the caller queued on `stream` (the work that
+    // produces d_scalars).  The call returns after the result has landed, so nothing of it is left running for the caller to order after.
+    ZK_HIP(hipEventRecord(h->ev_in, (hipStream_t)stream));
+    ZK_HIP(hipStreamWaitEvent(msm_job_stream(h->job), h->ev_in, 0));
     MsmBases b; b.p = h->table.buf.p; b.g2 = false; b.level_stride = h->table.n; b.p29 = h->table.rec29.p;
     G1 r;
     if (msm_job_launch(h->job, &b, 1, (const uint32_t *)d_scalars, n, (scalars_mont & ZKG_SCALARS_MONT) != 0, nullptr) || msm_job_finish(h->job, &r, nullptr)) return ZKG_ERROR;

@@ -145,7 +145,11 @@ static int libsnark_trusted_setup_impl(zklaim_ctx *ctx) {
     lap("keys generated");
     ctx->vk = vk; ctx->vk_size = vk_len; ctx->pk = pk; ctx->pk_size = pk_len;                     // libsnark_wrapper.cpp:207-208
     std::shared_ptr<zkg_crs> shared = share_crs(crs);
-    static const bool no_warm = getenv("ZKG_SEAM_NO_WARM") != nullptr;
+    // ZKG_SEAM_ISSUER_ONLY: a process that only issues keys (never proves) keeps nothing on the GPU after the call — no resident key
+    // (2.4 GB at m = 2^20), no warm-up proof; a prover that later receives the blob loads it in its first libsnark_prove (14 - 86 ms)
+    static const bool issuer_only = getenv("ZKG_SEAM_ISSUER_ONLY") != nullptr;
+    static const bool no_warm = getenv("ZKG_SEAM_NO_WARM") != nullptr || issuer_only;
+    if (issuer_only) { lap("issuer only: key not kept"); return ZKLAIM_OK; }
     if (!no_warm) {
         // Key preparation that needs a witness' SHAPE: which variables are not bits decides what the witness tables cover, and the first
         // proof on a key allocates every stream's workspace.  The ctx at hand names a credential of exactly this shape (the issuer's

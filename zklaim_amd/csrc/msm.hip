@@ -1238,14 +1238,16 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
             job->converted_aside = true;
         }
     }
-    if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return ZKG_ERROR;
+    // an error return after the fork must not leave the side stream reading the caller's bases (a synchronous caller may free them next)
+    auto fail = [&] { if (job->converted_aside) { (void)hipStreamSynchronize(job->aux); job->converted_aside = false; } return ZKG_ERROR; };
+    if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return fail();
     if (job->merge > 1) {
         for (int k = 0; k < 2; ++k) for (int i = 0; i < job->group[k].nsets; ++i) by_field[k][i].level_stride *= job->merge;
     }
     lap("sort enqueued");
     const bool timed_field_g2 = job->group[0].nsets == 0;                       // the kernel timer follows the first G1 launch (G2 when there is no G1 set)
-    if (job->group[1].nsets && launch_accumulate<Fq2>(job, job->group[1], by_field[1], d_gather, job == &g_default_job && timed_field_g2)) return ZKG_ERROR;   // G2 first: the longer chains
-    if (job->group[0].nsets && launch_accumulate<Fq>(job, job->group[0], by_field[0], d_gather, job == &g_default_job)) return ZKG_ERROR;
+    if (job->group[1].nsets && launch_accumulate<Fq2>(job, job->group[1], by_field[1], d_gather, job == &g_default_job && timed_field_g2)) return fail();   // G2 first: the longer chains
+    if (job->group[0].nsets && launch_accumulate<Fq>(job, job->group[0], by_field[0], d_gather, job == &g_default_job)) return fail();
     lap("accum enqueued");
     return ZKG_OK;
 }

@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "../../include/zkg.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -242,13 +243,27 @@ __global__ void k_set_one(Fr *z) { if (threadIdx.x == 0 && blockIdx.x == 0) z[0]
 // listed 0 or 1 is a bit like any other), lists the others and tells the host how many there are — the last workgroup to finish writes
 // into the pinned words, so no fill, classify or copy launch stands between the upload and the mat-vec.
 // words: [0] satisfiability flag, [1] k_r1cs_check's ticket, [2] k_scatter_full's ticket, [3] bad listed entry; count: [0] listed, [1] a listed element misses the witness tables
+static constexpr uint32_t TAG_UNCLAIMED = 3;
 __global__ __launch_bounds__(256) void k_expand_tags(const uint8_t *tags, size_t n, Fr *z /* z[0] is the constant */, uint8_t *wtags, uint32_t *words, uint32_t *count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { z[0] = Fr::one(); wtags[0] = 1; words[0] = 0; words[1] = 0; words[2] = 0; words[3] = 0; count[0] = 0; count[1] = 0; }
     if (i >= n) return;
     const bool one = tags[i] == 1;
     z[i + 1] = one ? Fr::one() : Fr::zero();                                   // listed entries are overwritten by k_scatter_full
-    wtags[i + 1] = one ? 1 : 0;
+    wtags[i + 1] = one ? 1 : (tags[i] == 2 ? TAG_UNCLAIMED : 0);               // a tag-2 variable waits for its one listing (never listed: counts as zero; no consumer reads 3 as a bit)
+}
+// A listed variable's tag byte goes from TAG_UNCLAIMED to the tag of its value exactly once: the second listing of an index finds the byte
+// taken and fails the call (it used to put the position into the gather list twice: A / B / L counted z[pos] twice while H saw it once —
+// ZKG_OK with an invalid proof).  Byte-wide compare-and-swap on the containing word; the neighbours' bytes may change under it.
+ZK_D bool claim_listed_tag(uint8_t *wtags, uint32_t pos, uint32_t tag) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(wtags + (pos & ~3u)); const uint32_t sh = 8 * (pos & 3u);
+    uint32_t old = atomicOr(w, 0u);
+    for (;;) {
+        if (((old >> sh) & 0xffu) != TAG_UNCLAIMED) return false;
+        const uint32_t want = (old & ~(0xffu << sh)) | (tag << sh), prev = atomicCAS(w, old, want);
+        if (prev == old) return true;
+        old = prev;
+    }
 }
 __global__ __launch_bounds__(256) void k_scatter_full(const uint32_t *idx, const Fr *vals, size_t cnt, size_t n, Fr *z, const uint8_t *tags, uint8_t *wtags,
                                                       uint32_t *listed, uint32_t *count, uint32_t *words, const uint32_t *subset_pos, uint32_t *host_words) {
@@ -264,7 +279,8 @@ __global__ __launch_bounds__(256) void k_scatter_full(const uint32_t *idx, const
             for (int j = 0; j < 8; ++j) { any |= val.v[j]; diff |= val.v[j] ^ FrParams::ONE[j]; }
             tag = any == 0 ? 0u : (diff == 0 ? 1u : 2u);
             pos = v + 1;
-            z[pos] = val; wtags[pos] = (uint8_t)tag;
+            if (claim_listed_tag(wtags, pos, tag)) z[pos] = val;
+            else { or_and_wait(words + 3); tag = 0; }                           // listed twice: the call fails (words[3]), nothing is listed again
         }
     }
     const unsigned long long mask = __ballot(tag == 2);
@@ -410,7 +426,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
     if (S.ready) return ZKG_OK;
     const size_t n = crs->n, m = crs->m;
     bool ok = S.z.reserve((n + 1) * 32) == 0 && S.aABC.reserve(3 * m * 32) == 0 && S.flag.reserve(16) == 0 && S.ntt_scratch.reserve(3 * m * NTT_SCRATCH_BYTES) == 0 &&
-              S.wtags.reserve(n + 1) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(8) == 0 &&
+              S.wtags.reserve(n + 8) == 0 && S.wlisted.reserve((n + 1) * 4) == 0 && S.wcount.reserve(8) == 0 &&
               hip_ok(hipHostMalloc((void **)&S.flag_host, 64, hipHostMallocDefault), "hipHostMalloc", __FILE__, __LINE__);
     if (ok) {
         int prio_lo = 0, prio_hi = 0;
@@ -577,6 +593,9 @@ void zkg_crs_free(zkg_crs *crs) {
 
 uint32_t zkg_crs_num_variables(const zkg_crs *crs) { return crs ? crs->n : 0; }
 
+// the largest number of proofs any one key has had in flight at once since the last reset (zkg_prover_peak_in_flight): what a test of
+// "callers run side by side" can assert without a stopwatch
+static std::atomic<int> g_peak_in_flight{0};
 // A caller's hold on one prover slot of a key (see zkg_crs): blocks until a slot is free and no table extension is pending.
 struct SlotLease {
     zkg_crs *crs; int i = -1;
@@ -593,6 +612,7 @@ struct SlotLease {
                 for (int k = 0; k < max_slots && pick < 0; ++k) if (!crs->busy[k]) pick = k;              // not created yet
                 if (pick >= 0) {
                     crs->busy[pick] = true; ++crs->leases;
+                    { int seen = g_peak_in_flight.load(std::memory_order_relaxed); while (crs->leases > seen && !g_peak_in_flight.compare_exchange_weak(seen, crs->leases)) {} }
                     if (crs->slot[pick].ready) { i = pick; return; }
                     lk.unlock();
                     const int rc = slot_create(crs, crs->slot[pick]);                                     // device allocations: outside the lock
@@ -810,7 +830,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     auto witness_fn = [&]() -> int {
         ZK_HIP(hipEventSynchronize(S.ev[0]));
         const size_t listed = S.flag_host[1];
-        if (S.flag_host[3]) { set_error("prover: a listed witness index is out of range or not tagged 2"); return ZKG_ERROR; }
+        if (S.flag_host[3]) { set_error("prover: a listed witness index is out of range, not tagged 2 or listed twice"); return ZKG_ERROR; }
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
         const uint8_t *tags = S.wtags.as<uint8_t>(); const uint32_t *gather = S.wlisted.as<uint32_t>(), *z = S.z.as<uint32_t>();
         if (listed && (S.flag_host[2] || !crs->sub.count)) {
@@ -1026,6 +1046,11 @@ int zkg_crs_shard_h(zkg_crs *crs, const int *devices, int ndev) {
     catch (...) { set_error("zkg_crs_shard_h: unexpected exception"); return ZKG_ERROR; }
 }
 
+int zkg_prover_peak_in_flight(int reset) {
+    const int v = g_peak_in_flight.load();
+    if (reset) g_peak_in_flight.store(0);
+    return v;
+}
 int zkg_prove_stage_ms(const zkg_crs *crs, float ms[8]) {
     if (!crs || !ms) return ZKG_ERROR;
     for (int i = 0; i < 8; ++i) ms[i] = crs->stage_ms[i];
