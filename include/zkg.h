@@ -288,7 +288,8 @@ void zkg_compat_reset(void);
  *      input and op 5's output (canonical); outputs are fully reduced.  b is read by ops 0-2 only.
  *      Fq only, ops 10-14: the same arithmetic on the 9 x 29-bit representation of the bucket-accumulation kernel (csrc/fq29.hip.hpp),
  *      entered and left through its conversions: 10 mul, 11 add, 12 sub, 13 a if a != b else 0 (its zero test), 14 the composite
- *      (b-a)(a-b) - (b-a)^2 - 2ab with unnormalised intermediate sums, as the mixed addition chains them.                          */
+ *      (b-a)(a-b) - (b-a)^2 - 2ab with unnormalised intermediate sums, as the mixed addition chains them, 15 the inverse of 3a
+ *      (safegcd divsteps on 30-bit limbs, f29::inverse: what the batched-affine accumulation shares across a workgroup; 0 -> 0).     */
 int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 
 /* known-answer hook for the 29-bit group law of the bucket-reduction kernels (csrc/fq29.hip.hpp, xyzz29_add_quad): on the GPU,

@@ -69,6 +69,7 @@ def test_fq_29bit_representation_vs_integers(zkg):
     assert ints(zkg.field_op(0, 12, am, bm), p) == [(x - y) % p for x, y in zip(pa, pb)]
     assert ints(zkg.field_op(0, 13, am, bm), p) == [x if x != y else 0 for x, y in zip(pa, pb)]
     assert ints(zkg.field_op(0, 14, am, bm), p) == [((y - x) * (x - y) - (y - x) ** 2 - 2 * x * y) % p for x, y in zip(pa, pb)]
+    assert ints(zkg.field_op(0, 15, am, bm), p) == [pow(3 * x, -1, p) if x else 0 for x in pa]        # f29::inverse (safegcd divsteps), 0 -> 0
     # outputs are canonical limbs (below q), not merely congruent
     out = zkg.field_op(0, 10, am, bm)
     assert all(v < p for v in ints(out))

@@ -251,3 +251,66 @@ def test_resident_bases_with_window_tables_equal_the_plain_msm(zkg, oracle, n):
         h.msm(d_sc.data_ptr())
     h.n = n
     h.free()
+
+
+def _with_env(name, value, fn):
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = str(value)
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+def test_batched_affine_levels_match_the_plain_accumulation(zkg, oracle, levels):
+    """ZKG_ACCUM_BA = levels (csrc/msm_ba.inc): the bucket lists summed as a pairwise tree of batched AFFINE additions (Montgomery's trick
+    shared by a workgroup, safegcd inversion) before the XYZZ accumulation — the same point as libff's multi_exp_inner<BDLO12> loop
+    (snark.cpp:126), bit for bit: uniform scalars against the oracle, and every exceptional pair inside the batch — equal points
+    (tangent), P + (-P), infinity as an operand, infinity as a result feeding the next level."""
+    from util import Q, from_limbs
+    n = 20000
+    _, bases, _ = dev_bases_g1(zkg, n, 0xBA0 + levels)
+    sc = random_fr_canonical(n, 0xBA1 + levels)
+    exp = oracle.msm_g1(bases, sc)
+    assert np.array_equal(_with_env("ZKG_ACCUM_BA", levels, lambda: zkg.msm_g1(bases, sc)), exp)
+    assert np.array_equal(_with_env("ZKG_BA_K", 6, lambda: _with_env("ZKG_ACCUM_BA", levels, lambda: zkg.msm_g1(bases, sc))), exp)
+    # groups of four equal scalars land in one bucket; their bases are chosen so that neighbours in the bucket's list are equal, opposite
+    # or at infinity (the order inside a bucket is the sort's, so several pairings of each group occur)
+    n = 8192
+    _, bases, _ = dev_bases_g1(zkg, n, 0xBA2)
+    sc = np.repeat(random_fr_canonical(n // 4, 0xBA3 + levels), 4, axis=0)
+
+    def negated(b):
+        out = b.copy()
+        out[4:] = limbs((Q - from_limbs(b[4:])) % Q)
+        return out
+    for g in range(n // 4):
+        p, q_ = bases[4 * g].copy(), bases[4 * g + 1].copy()
+        kind = g % 4
+        if kind == 0:
+            bases[4 * g: 4 * g + 4] = p
+        elif kind == 1:
+            bases[4 * g + 1] = negated(p); bases[4 * g + 2] = q_; bases[4 * g + 3] = 0
+        elif kind == 2:
+            bases[4 * g + 1] = q_; bases[4 * g + 2] = negated(q_); bases[4 * g + 3] = negated(p)
+        else:
+            bases[4 * g] = 0; bases[4 * g + 1] = 0; bases[4 * g + 2] = p; bases[4 * g + 3] = p
+    exp = oracle.msm_g1(bases, sc)
+    assert np.array_equal(zkg.msm_g1(bases, sc), exp)
+    assert np.array_equal(_with_env("ZKG_ACCUM_BA", levels, lambda: zkg.msm_g1(bases, sc)), exp)
+
+
+def test_batched_affine_levels_at_2p18(zkg):
+    """the same switch at a size where the levels are most of the work (2^18 points, 16-bit windows): equal to the default path"""
+    import torch
+    n = 1 << 18
+    d_bases, _, _ = dev_bases_g1(zkg, n, 0xBA9)
+    d_sc = torch.from_numpy(random_fr_canonical(n, 0xBAA).view(np.int64)).cuda()
+    exp = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)
+    for levels in (2, 3):
+        assert np.array_equal(_with_env("ZKG_ACCUM_BA", levels, lambda: zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)), exp)

@@ -26,13 +26,15 @@ def build(force=False, verbose=False):
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     # shared inputs (headers, generated streams, the C ABI): a change there recompiles everything; otherwise only the sources that changed
-    shared = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if not f.endswith(".hip")] + \
+    private = {"msm_ba.inc": "msm.hip"}      # included by one source only
+    shared = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if not f.endswith(".hip") and f not in private] + \
              [os.path.join(HERE, "..", "include", f) for f in ("zkg.h", "zklaim_abi.h")] + [os.path.abspath(__file__)]
     shared_t = max(os.path.getmtime(f) for f in shared)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(shared_t, os.path.getmtime(os.path.join(CSRC, src))):
+        own = [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f, owner in private.items() if owner == src and os.path.exists(os.path.join(CSRC, f))]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max([shared_t] + [os.path.getmtime(f) for f in own]):
             continue
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

@@ -164,10 +164,11 @@ template <class F> __global__ __launch_bounds__(64) void k_field_op(int op, cons
     }
     if constexpr (std::is_same<F, Fq>::value) {
         // the 29-bit representation of the accumulation kernel (fq29.hip.hpp), entered and left through its own conversions
-        if (op >= 10 && op <= 14) {
+        if (op >= 10 && op <= 15) {
             const Fq29 xa = f29::to29(x), yb = f29::to29(y);
             Fq29 r = xa;
             if (op == 10) r = f29::mul(xa, yb);
+            else if (op == 15) r = f29::inverse(f29::norm(f29::add(f29::add(xa, xa), xa)));      // 1 / (3 a): an unreduced sum as input
             else if (op == 11) r = f29::norm(f29::add(xa, yb));
             else if (op == 12) r = f29::norm(f29::sub(xa, f29::S2_1, yb));
             else if (op == 14) {                 // a chain as the mixed addition builds them: unnormalised differences into products
@@ -442,7 +443,7 @@ int zkg_g2_fixed_base_dev(const uint64_t base[16], const void *d_scalars, size_t
 
 int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
     REQUIRE_INIT();
-    const bool binary = (op >= 0 && op <= 2) || (op >= 10 && op <= 14 && field == 0), known = binary || op == 3 || op == 6 || op == 7 || ((op == 4 || op == 5) && field != 2);
+    const bool binary = (op >= 0 && op <= 2) || (op >= 10 && op <= 14 && field == 0), known = binary || op == 3 || op == 6 || op == 7 || (op == 15 && field == 0) || ((op == 4 || op == 5) && field != 2);
     if (!known || field < 0 || field > 2 || !a || !out || (binary && !b)) { set_error("zkg_field_op: bad argument"); return ZKG_ERROR; }
     if (!n) return ZKG_OK;
     if (field == 0) return field_op_run<Fq>(op, a, binary ? b : nullptr, n, out);

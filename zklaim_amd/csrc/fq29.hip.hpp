@@ -135,6 +135,135 @@ ZK_D Fq from29(const Fq29 &a) {            // a: digits, value below 13 p
     return Fq::reduce_once(w);
 }
 
+
+// ---- inversion: constant-time safegcd (Bernstein-Yang divsteps; the layout of libsecp256k1's modinv32: nine signed 30-bit limbs, 30
+//      divsteps per round on the low limbs, the 2 x 2 transition matrix applied to (f, g) and — modulo q — to (d, e)).  libff's
+//      Fp_model::inverse() is what the reference reaches through to_affine / batch inversion; here the inversion feeds Montgomery's trick in
+//      the batched-affine accumulation (msm.hip), where ONE wavefront inverts 64 shared products for its workgroup: a Fermat chain
+//      (254 squarings + ~50 products = 300 product-times, 0.13 ms of latency on a lone wavefront) would stall the workgroup for longer than
+//      its additions take; 20 rounds of 30 divsteps are ~45 product-times, and every lane finishes in the same round count.
+//      Proven bound for 256-bit inputs: 590 divsteps (20 rounds); random inputs are through after 18 — the loop leaves when every lane of
+//      the wavefront has g = 0 (further rounds change nothing: with g = 0 a round is the identity on f and d).
+__device__ static constexpr int32_t Q30[9] = {0x187cfd47, 0x3082305b, 0x071ca8d3, 0x205aa45a, 0x01585d97, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
+static constexpr uint32_t Q30_INV = 0x1b799c77u;                  // q^-1 mod 2^30
+// R'^3 mod q: mont(X^-1, R3) = X^-1 R'^2 = (x R')^-1 R'^2 = x^-1 R', the representation of 1 / x
+__device__ static constexpr uint32_t R3[9] = {0x0e2312b2u, 0x16c05ca2u, 0x0bc84389u, 0x1cdf310bu, 0x11adafddu, 0x032e568eu, 0x1d6ae48cu, 0x10d4cd1fu, 0x0026c2d2u};
+struct Trans30 { int32_t u, v, q, r; };
+ZK_D int32_t divsteps30(int32_t zeta, uint32_t f, uint32_t g, Trans30 &t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+#pragma unroll 6
+    for (int i = 0; i < 30; ++i) {
+        uint32_t c1 = (uint32_t)(zeta >> 31);
+        const uint32_t c2 = 0u - (g & 1u);
+        const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+        g += x & c2; q += y & c2; r += z & c2;
+        c1 &= c2;
+        zeta = (int32_t)(((uint32_t)zeta ^ c1) - 1u);
+        f += g & c1; u += q & c1; v += r & c1;
+        g >>= 1; u <<= 1; v <<= 1;
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return zeta;
+}
+ZK_D void update_de30(int32_t (&d)[9], int32_t (&e)[9], const Trans30 &t) {
+    constexpr int32_t M30 = 0x3fffffff;
+    const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+    const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0], ce = (int64_t)q * d[0] + (int64_t)r * e[0];
+    md -= (int32_t)((Q30_INV * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+    me -= (int32_t)((Q30_INV * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+    cd += (int64_t)Q30[0] * md; ce += (int64_t)Q30[0] * me;
+    cd >>= 30; ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)Q30[i] * md;
+        ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)Q30[i] * me;
+        d[i - 1] = (int32_t)cd & M30; cd >>= 30;
+        e[i - 1] = (int32_t)ce & M30; ce >>= 30;
+    }
+    d[8] = (int32_t)cd; e[8] = (int32_t)ce;
+}
+ZK_D void update_fg30(int32_t (&f)[9], int32_t (&g)[9], const Trans30 &t) {
+    constexpr int32_t M30 = 0x3fffffff;
+    const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+    int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0], cg = (int64_t)q * f[0] + (int64_t)r * g[0];
+    cf >>= 30; cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        cf += (int64_t)u * f[i] + (int64_t)v * g[i];
+        cg += (int64_t)q * f[i] + (int64_t)r * g[i];
+        f[i - 1] = (int32_t)cf & M30; cf >>= 30;
+        g[i - 1] = (int32_t)cg & M30; cg >>= 30;
+    }
+    f[8] = (int32_t)cf; g[8] = (int32_t)cg;
+}
+// 1 / a in the same representation.  a: digits, value below 2^261 (anything a product or norm() returns); a multiple of q returns zero.
+// Every lane of the wavefront must call it (the early exit is a wavefront vote).
+ZK_D Fq29 inverse(const Fq29 &a) {
+    constexpr int32_t M30 = 0x3fffffff;
+    int32_t g[9], f[9], d[9], e[9];
+    // the integer X = sum v[i] 2^(29 i), repacked into 30-bit limbs, then brought below q: X < 2^261 = 169.3 q is too large for the divstep
+    // bound, so one product by R' mod q first (mont(X, ONE) = X R' / R' = X mod q, below 2 q) and a conditional subtraction
+    Fq29 one; for (int i = 0; i < 9; ++i) one.v[i] = ONE[i];
+    const Fq29 xr = mul(a, one);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 30 * i, j = bit / 29, sh = bit - 29 * j;
+        uint32_t w = xr.v[j] >> sh;
+        if (j + 1 < 9) w |= xr.v[j + 1] << (29 - sh);
+        g[i] = i < 8 ? (int32_t)(w & (uint32_t)M30) : (int32_t)w;
+    }
+    {   // g - q if that is not negative
+        int32_t t[9], c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const int32_t s = g[i] - Q30[i] + c; t[i] = i < 8 ? s & M30 : s; c = s >> 30; }
+        const bool neg = t[8] < 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = neg ? g[i] : t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { f[i] = Q30[i]; d[i] = 0; e[i] = 0; }
+    e[0] = 1;
+    int32_t zeta = -1;
+    for (int it = 0; it < 20; ++it) {
+        Trans30 t;
+        zeta = divsteps30(zeta, (uint32_t)f[0], (uint32_t)g[0], t);
+        update_de30(d, e, t);
+        update_fg30(f, g, t);
+        if (it >= 15) {
+            int32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) any |= g[i];
+            if (__all(any == 0)) break;
+        }
+    }
+    // d = +-1 / X: add q if negative, negate by the sign of f (= +-1), propagate, add q again if needed
+    {
+        const int32_t add = d[8] >> 31, ngt = f[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { int32_t x = d[i] + (Q30[i] & add); d[i] = (x ^ ngt) - ngt; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+        const int32_t add2 = d[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] += Q30[i] & add2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+    }
+    // a multiple of q has no inverse: f ends as +-q, d as 0 mod q — return exact zero limbs (callers test for all-zero)
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {                                               // 30-bit limbs -> 29-bit digits
+        const int bit = 29 * i, j = bit / 30, sh = bit - 30 * j;
+        uint32_t w = (uint32_t)d[j] >> sh;
+        if (j + 1 < 9 && sh > 1) w |= (uint32_t)d[j + 1] << (30 - sh);
+        r.v[i] = i < 8 ? w & Fq29::M : w;
+    }
+    Fq29 r3; for (int i = 0; i < 9; ++i) r3.v[i] = R3[i];
+    return mul(r, r3);
+}
+
 }  // namespace f29
 
 // a base point as the accumulation kernel gathers it: x, y as digits of x R', y R' (18 words), a flag word (1 = infinity) and padding to

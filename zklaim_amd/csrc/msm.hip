@@ -564,6 +564,8 @@ __global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *b
     else buckets[gb] = XYZZ<Fq>{f29::from29(acc.x), f29::from29(acc.y), f29::from29(acc.zz), f29::from29(acc.zzz)};
 }
 
+#include "msm_ba.inc"
+
 // A point in LDS, padded to 144 B (G1) / 272 B (G2): at the natural 128 / 256-byte stride consecutive points start on the same four banks.
 // Measured effect: k_bucket_reduce 363 -> 354 us at 2^19 buckets — the kernels that use it are bound by the multiplications of their
 // addition chains (two wavefronts per SIMD: 1.16 us per dependent product), not by the LDS port.
@@ -905,6 +907,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uin
 struct MsmGroup {                   // the base sets of one field in a launch: accumulators and the host landing zone of their chunk results
     DevBuf buckets, folded, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
     DevBuf bases29;                                    // a plain G1 set's bases as 80-byte 29-bit records (k_bases_to29), rebuilt per launch
+    DevBuf ba_start, ba_pre, ba_planes;                // batched-affine levels (msm_ba.inc): bucket-start bits, prefix-product scratch, the levels' coordinate planes
     void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false; int nsets = 0;
     int out_index[MSM_MAX_SETS] = {0};                 // position of each set among the launch's sets of this field
     uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry per set: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
@@ -917,7 +920,7 @@ struct MsmGroup {                   // the base sets of one field in a launch: a
         return 0;
     }
     void release() {
-        for (DevBuf *b : {&buckets, &folded, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials, &bases29}) b->release();
+        for (DevBuf *b : {&buckets, &folded, &red_out, &heavy_items, &heavy_buckets, &heavy_counters, &heavy_partials, &bases29, &ba_start, &ba_pre, &ba_planes}) b->release();
         if (host_red) (void)hipHostFree(host_red);
         host_red = nullptr; host_cap = 0;
     }
@@ -993,7 +996,49 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         }
     }
     if (time_it) g_dominant_timer.begin(s);
+    bool done_ba = false;
     if constexpr (sizeof(F) == sizeof(Fq)) {
+        // batched-affine levels in front of the accumulation (msm_ba.inc): ZKG_ACCUM_BA = number of levels (1..4), ZKG_BA_K = nodes per lane
+        // (read per launch, not once: the parity tests switch it inside one process)
+        const char *e_ba = getenv("ZKG_ACCUM_BA"), *e_k = getenv("ZKG_BA_K");
+        const int ba_levels = e_ba ? std::max(0, std::min((int)ba::MAX_LEVELS, atoi(e_ba))) : 0;
+        const int ba_k = e_k ? std::max(2, std::min(32, atoi(e_k) & ~1)) : 16;
+        if (use29 && stride29 == 0 && ba_levels > 0 && n_entries_max >= 4096) {
+            const int R = ba_levels, K = ba_k;
+            const size_t per_wg = (size_t)ba::THREADS * K, words_start = n_entries_max / 32 + 2;
+            size_t stride[ba::MAX_LEVELS + 1] = {0}, plane_words = 0, grid1 = 0;
+            for (int l = 1; l <= R; ++l) {
+                const size_t nodes = (n_entries_max >> l) + 1, grid = (nodes + per_wg - 1) / per_wg;
+                stride[l] = grid * per_wg;                                     // a multiple of 512: every lane's node index stays inside the plane
+                plane_words += 18 * stride[l];
+                if (l == 1) grid1 = grid;
+            }
+            if (gr.ba_start.reserve(words_start * 4) || gr.ba_pre.reserve(grid1 * K * 9 * ba::THREADS * 4) || gr.ba_planes.reserve(plane_words * 4)) return ZKG_ERROR;
+            uint32_t *start = gr.ba_start.as<uint32_t>(), *planes = gr.ba_planes.as<uint32_t>();
+            ZK_HIP(hipMemsetAsync(start, 0, words_start * 4, s));
+            hipLaunchKernelGGL(k_ba_starts, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, s, job->counts.as<uint32_t>(), job->offsets.as<uint32_t>(), total_buckets, start);
+            BaPlanes pl{}; size_t at = 0;
+            for (int l = 1; l <= R; ++l) { pl.X[l] = planes + at; pl.Y[l] = planes + at + 9 * stride[l]; pl.stride[l] = stride[l]; at += 18 * stride[l]; }
+            const uint32_t *n_entries = job->offsets.as<uint32_t>() + total_buckets;
+            for (int l = 1; l <= R; ++l) {
+                const unsigned grid = (unsigned)(stride[l] / per_wg);
+                uint32_t *oX = const_cast<uint32_t *>(pl.X[l]), *oY = const_cast<uint32_t *>(pl.Y[l]);
+                if (l == 1) {
+                    ba::Src src{rec29, job->sorted.as<uint32_t>(), nullptr, nullptr, 0};
+                    hipLaunchKernelGGL(k_ba_level<true>, dim3(grid), dim3(ba::THREADS), 0, s, src, start, n_entries, (uint32_t)l, K, oX, oY, stride[l], gr.ba_pre.as<uint32_t>());
+                } else {
+                    ba::Src src{nullptr, nullptr, pl.X[l - 1], pl.Y[l - 1], stride[l - 1]};
+                    hipLaunchKernelGGL(k_ba_level<false>, dim3(grid), dim3(ba::THREADS), 0, s, src, start, n_entries, (uint32_t)l, K, oX, oY, stride[l], gr.ba_pre.as<uint32_t>());
+                }
+            }
+            hipLaunchKernelGGL(k_bucket_accum_ba, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, job->sorted.as<uint32_t>(), pl, R, job->offsets.as<uint32_t>(),
+                               job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(),
+                               gr.heavy_counters.as<uint32_t>(), L);
+            done_ba = true;
+        }
+    }
+    if (done_ba) {}
+    else if constexpr (sizeof(F) == sizeof(Fq)) {
         static const int waves29 = getenv("ZKG_ACC29_WAVES") ? atoi(getenv("ZKG_ACC29_WAVES")) : 2;               // tuning aid
         if (use29 && waves29 == 3)
             hipLaunchKernelGGL(k_bucket_accum29<3>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
@@ -1004,7 +1049,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                                job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(),
                                gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     }
-    if (use29) {}
+    if (use29 || done_ba) {}
     else if (plain)
         hipLaunchKernelGGL((k_bucket_accum<F, true>), dim3((unsigned)((lanes + 255) / 256), ns), dim3(256), 0, s,
                            views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
