@@ -133,6 +133,13 @@ int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
                    uint64_t out_jac[12], void *stream);
 int zkg_msm_g2_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont,
                    uint64_t out_jac[24], void *stream);
+/* Bases resident on the device, scalars in HOST memory: the step SURVEY.md section 8(d) times ("wall clock around the call incl. H2D of
+ * scalars; bases resident") — what a prover with a resident key does per proof when the scalars come from the host.  `scalars`: n x 4
+ * canonical limbs (or Montgomery with ZKG_SCALARS_MONT) in host memory; page-locked memory (hipHostMalloc / hipHostRegister) lets the upload
+ * run under the work: from 2^19 points on the job is cut by points into four pieces whose uploads overlap the sort and accumulation of the
+ * pieces before them, all accumulating into one set of buckets (pageable memory works, without the overlap).  Same point as zkg_msm_g1_dev on
+ * the uploaded vector, bit for bit.  `stream` as in zkg_msm_g1_dev; the result is in out_jac when the call returns.                      */
+int zkg_msm_g1_host_scalars(const void *d_bases, const uint64_t *scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream);
 /* Fixed bases kept resident WITH their per-window tables (level w = 2^(c w) P_i; c = 16 from 2^15 points on: 16 x the bases' memory plus the
  * same again as 29-bit records) — what the prover builds for a key's H query, offered for any fixed G1 base set (libff has no counterpart; its
  * multi_exp takes the bases as they are).  Every window's digit then weighs the same: one bucket set, one reduction, no doublings on the

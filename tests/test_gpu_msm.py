@@ -314,3 +314,30 @@ def test_batched_affine_levels_at_2p18(zkg):
     exp = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)
     for levels in (2, 3):
         assert np.array_equal(_with_env("ZKG_ACCUM_BA", levels, lambda: zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)), exp)
+
+
+@pytest.mark.parametrize("n", [3000, (1 << 19) + 777, 1 << 20])
+def test_host_scalars_pieces_equal_the_resident_msm(zkg, oracle, n):
+    """zkg_msm_g1_host_scalars (bases resident, scalars uploaded from pinned host memory in pieces under the work; every piece accumulates
+    into the same 29-bit buckets, one reduction at the end): the same point as zkg_msm_g1_dev on the uploaded vector, for uniform scalars
+    and for a vector whose digits pile up in a few buckets (heavy buckets continued from piece to piece), pageable memory included."""
+    import torch
+    d_bases, bases, _ = dev_bases_g1(zkg, n, 0x4051 + n)
+    sc = random_fr_canonical(n, 0x4052 + n)
+    h_sc = torch.from_numpy(sc.view(np.int64)).pin_memory()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    exp = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n)
+    if n <= 3000:
+        assert np.array_equal(exp, oracle.msm_g1(bases, sc))
+    assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_sc.data_ptr(), n), exp)
+    assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), sc.ctypes.data, n), exp)          # pageable host memory
+    # a third of the scalars equal (one giant bucket per window, in every piece), some zero, r - 1, a duplicated base and a base at infinity
+    sc2 = sc.copy(); rng = np.random.default_rng(n); kind = rng.integers(0, 100, n)
+    sc2[kind < 33] = sc2[0]; sc2[(kind >= 33) & (kind < 40)] = 0; sc2[n - 1] = limbs(R - 1); sc2[n // 2] = limbs(R - 1)
+    bases[n // 2] = bases[n - 1]; bases[5] = 0
+    d_bases2 = torch.from_numpy(bases.view(np.int64)).cuda()
+    h_sc2 = torch.from_numpy(sc2.view(np.int64)).pin_memory()
+    d_sc2 = torch.from_numpy(sc2.view(np.int64)).cuda()
+    exp2 = zkg.msm_g1_dev(d_bases2.data_ptr(), d_sc2.data_ptr(), n)
+    assert np.array_equal(zkg.msm_g1_host_scalars(d_bases2.data_ptr(), h_sc2.data_ptr(), n), exp2)
+    assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_sc.data_ptr(), n), exp)       # and the job is clean afterwards

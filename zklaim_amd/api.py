@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
     "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h", "zkg_msm_g1_bases_upload", "zkg_msm_g1_resident", "zkg_msm_g1_bases_free",
-    "zkg_prover_peak_in_flight",
+    "zkg_prover_peak_in_flight", "zkg_msm_g1_host_scalars",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -226,6 +226,14 @@ def msm_g1_dev(d_bases, d_scalars, n, scalars_mont=False, stream=0, mostly_bits=
     out = np.zeros(12, np.uint64)
     flags = (SCALARS_MONT if scalars_mont else 0) | (SCALARS_MOSTLY_BITS if mostly_bits else 0)
     _check(lib().zkg_msm_g1_dev(_vp(d_bases), _vp(d_scalars), C.c_size_t(n), flags, _p(out), _vp(stream)), "zkg_msm_g1_dev")
+    return out
+
+
+def msm_g1_host_scalars(d_bases, scalars_host_ptr, n, scalars_mont=False, stream=0):
+    """zkg_msm_g1_host_scalars: bases resident (device pointer), scalars at a HOST address (pinned memory lets the upload overlap the work)"""
+    out = np.zeros(12, np.uint64)
+    lib().zkg_msm_g1_host_scalars.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    _check(lib().zkg_msm_g1_host_scalars(_vp(d_bases), _vp(scalars_host_ptr), C.c_size_t(n), SCALARS_MONT if scalars_mont else 0, _p(out), _vp(stream)), "zkg_msm_g1_host_scalars")
     return out
 
 

@@ -326,6 +326,14 @@ int zkg_msm_g1_dev(const void *d_bases, const void *d_scalars, size_t n, int sca
     store_norm(out_jac, r);
     return ZKG_OK;
 }
+int zkg_msm_g1_host_scalars(const void *d_bases, const uint64_t *scalars, size_t n, int scalars_mont, uint64_t out_jac[12], void *stream) {
+    REQUIRE_INIT();
+    if (!out_jac || (n && (!d_bases || !scalars))) { set_error("zkg_msm_g1_host_scalars: bad argument"); return ZKG_ERROR; }
+    G1 r;
+    if (msm_g1_host_scalars((const G1Affine *)d_bases, (const uint32_t *)scalars, n, (scalars_mont & ZKG_SCALARS_MONT) != 0, &r, (hipStream_t)stream)) return ZKG_ERROR;
+    store_norm(out_jac, r);
+    return ZKG_OK;
+}
 int zkg_msm_g1_windows_dev(const void *d_bases, const void *d_scalars, size_t n, int scalars_mont, unsigned first_window, unsigned window_stride,
                            uint64_t out_jac[12], void *stream) {
     REQUIRE_INIT();

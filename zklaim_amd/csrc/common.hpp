@@ -157,6 +157,7 @@ int ones_sum_launch(OnesSum &o, const MsmBases *sets, int nsets, const uint8_t *
 // one heavy bucket, which is what libff's multi_exp_with_mixed_addition prefilter achieves.
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s, bool mostly_bits = false);
 int msm_g2(const G2Affine *d_bases, const uint32_t *d_scalars, size_t n, bool scalars_mont, G2 *out, hipStream_t s, bool mostly_bits = false);
+int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size_t n, bool scalars_mont, G1 *out, hipStream_t s);   // bases resident, scalars uploaded in pieces under the work
 // one digit/sort pass shared by several base sets (A, B_g1, B_g2 queries use the same scalars)
 int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2_bases, const uint32_t *d_scalars, size_t n,
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0 = 0, uint32_t ws = 1,   // w0, ws: window subset (see MsmGeom)

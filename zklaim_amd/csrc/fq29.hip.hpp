@@ -296,6 +296,38 @@ struct XYZZ29 {
     }
 };
 
+// A bucket accumulator as the 29-bit kernels keep it in memory between accumulation (also from one piece of a piece-wise job to the next)
+// and reduction: the four coordinates as digits under XYZZ29's invariants, 144 bytes = nine aligned 16-byte words; infinity: ZZ all zero.
+struct alignas(16) Bucket29 { uint32_t x[9], y[9], zz[9], zzz[9]; };
+ZK_D void store_bucket29(Bucket29 *dst, const XYZZ29 &a, bool inf) {
+    Bucket29 o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { o.x[i] = inf ? 0u : a.x.v[i]; o.y[i] = inf ? 0u : a.y.v[i]; o.zz[i] = inf ? 0u : a.zz.v[i]; o.zzz[i] = inf ? 0u : a.zzz.v[i]; }
+    uint4 *d = reinterpret_cast<uint4 *>(dst); const uint4 *s = reinterpret_cast<const uint4 *>(&o);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = s[i];
+}
+ZK_D Bucket29 load_bucket29_raw(const Bucket29 *src) {
+    Bucket29 o; uint4 *d = reinterpret_cast<uint4 *>(&o); const uint4 *s = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = s[i];
+    return o;
+}
+// the same from / to the 32-bit kernels' XYZZ<Fq> (heavy-bucket path: rare)
+ZK_D void store_bucket29(Bucket29 *dst, const XYZZ<Fq> &p) {
+    XYZZ29 a; const bool inf = p.is_inf();
+    if (!inf) { a.x = f29::to29(p.x.normalized()); a.y = f29::to29(p.y.normalized()); a.zz = f29::to29(p.zz.normalized()); a.zzz = f29::to29(p.zzz.normalized()); }
+    else a.x = a.y = a.zz = a.zzz = Fq29::zero();
+    store_bucket29(dst, a, inf);
+}
+ZK_D XYZZ<Fq> bucket29_to_xyzz(const Bucket29 &b) {
+    Fq29 x, y, zz, zzz; uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { x.v[i] = b.x[i]; y.v[i] = b.y[i]; zz.v[i] = b.zz[i]; zzz.v[i] = b.zzz[i]; any |= b.zz[i]; }
+    if (!any) return XYZZ<Fq>::inf().normalized();
+    return {f29::from29(x), f29::from29(y), f29::from29(zz), f29::from29(zzz)};
+}
+
 // ---- general addition on the 29-bit representation, shared by the four lanes of a DPP quad (the bucket reduction's chains) ------------
 // Same scheme as xyzz_add_quad (curve.hip.hpp): the lanes hold identical copies of both operands, each multiplies a different pair and the
 // products are broadcast back — 14 dependent products become 4 rounds — but a round costs a 29-bit product: 930 cycles instead of 1293 at

@@ -517,9 +517,13 @@ ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
 }
 // WAVES: wavefronts per SIMD the register allocation aims for (2: 204 registers, no spill; 3: 168 registers and a 232-byte spill frame)
 // level_stride != 0: `bases` is a per-window table (level w = 2^(c w) P_i, level_stride records apart) and a bucket reads its window's level
-template <int WAVES>
+// OUT29: the buckets are Bucket29 records (the plain G1 path: the reduction reads them without conversion) instead of canonical XYZZ<Fq>
+// (table launches: the fold in between works on 32-bit limbs).  resume (OUT29 only): the buckets hold the sums of the job's earlier pieces
+// (piece-wise multi-exponentiation, msm_g1_host_scalars): a lane continues its bucket's accumulator, an empty list leaves it alone, and a
+// heavy bucket's old value joins its parts in k_heavy_merge.
+template <int WAVES, bool OUT29>
 __global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
-                                                         size_t lanes, XYZZ<Fq> *buckets, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L) {
+                                                         size_t lanes, void *buckets_, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L, int resume) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
     const uint32_t heavy_t = heavy_threshold_dev(offsets, L.buckets, 1);
@@ -529,12 +533,23 @@ __global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *b
     if (end - k > heavy_t) {                                                    // as k_bucket_accum: long lists go to k_heavy_parts / k_heavy_merge
         uint32_t nparts = (end - k + HEAVY_S - 1) / HEAVY_S;
         uint32_t first = atomicAdd(&counters[0], nparts);
-        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb, nparts == 1}; }
-        if (nparts > 1) heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
+        const bool single = nparts == 1 && !resume;                             // a lone part may write its bucket itself only when nothing is there yet
+        for (uint32_t p = 0; p < nparts; ++p) { uint32_t a = k + p * HEAVY_S; items[first + p] = {a, a + HEAVY_S < end ? a + HEAVY_S : end, gb, single}; }
+        if (!single) heavy[atomicAdd(&counters[1], 1u)] = {gb, first, nparts};
         return;
     }
     XYZZ29 acc; bool inf = true;
     acc.x = acc.y = acc.zz = acc.zzz = Fq29::zero();
+    if constexpr (OUT29) {
+        if (resume) {
+            if (k >= end) return;                                               // nothing of this piece lands here: the bucket keeps its sum
+            const Bucket29 old = load_bucket29_raw(reinterpret_cast<const Bucket29 *>(buckets_) + gb);
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { acc.x.v[j] = old.x[j]; acc.y.v[j] = old.y[j]; acc.zz.v[j] = old.zz[j]; acc.zzz.v[j] = old.zzz[j]; any |= old.zz[j]; }
+            inf = any == 0;
+        }
+    }
     if (k < end) {
         // two loads deep: under the addition of entry k the base of entry k + 1 arrives (its address came from an index loaded one
         // addition earlier) and the index of entry k + 2 — neither the index nor the base is ever waited for right after it was requested
@@ -560,8 +575,12 @@ __global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *b
             if (k >= end) break;
         }
     }
-    if (inf) buckets[gb] = XYZZ<Fq>::inf().normalized();
-    else buckets[gb] = XYZZ<Fq>{f29::from29(acc.x), f29::from29(acc.y), f29::from29(acc.zz), f29::from29(acc.zzz)};
+    if constexpr (OUT29) store_bucket29(reinterpret_cast<Bucket29 *>(buckets_) + gb, acc, inf);
+    else {
+        XYZZ<Fq> *buckets = reinterpret_cast<XYZZ<Fq> *>(buckets_);
+        if (inf) buckets[gb] = XYZZ<Fq>::inf().normalized();
+        else buckets[gb] = XYZZ<Fq>{f29::from29(acc.x), f29::from29(acc.y), f29::from29(acc.zz), f29::from29(acc.zzz)};
+    }
 }
 
 #include "msm_ba.inc"
@@ -591,14 +610,19 @@ ZK_D void lds_tree_reduce(LdsPoint<F> *seg, uint32_t n, uint32_t tid, uint32_t n
 }
 
 // one wavefront per heavy part: 64 lanes stride over <= HEAVY_S entries, then a 6-level LDS tree
+// out29 (F = Fq only): the buckets are Bucket29 records (see k_bucket_accum29)
+template <class F> ZK_D void put_bucket(XYZZ<F> *buckets, uint32_t gb, const XYZZ<F> &v, int out29) {
+    if constexpr (sizeof(F) == sizeof(Fq)) { if (out29) { store_bucket29(reinterpret_cast<Bucket29 *>(buckets) + gb, v); return; } }
+    buckets[gb] = v;
+}
 template <class F>
 __global__ __launch_bounds__(256) void k_heavy_parts(const ViewSet<F> views, const uint32_t *sorted, const HeavyItem *items,
-                                                      const uint32_t *counters, XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
+                                                      const uint32_t *counters, XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L, int out29) {
     extern __shared__ unsigned char red_smem[];
     LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);            // 256 points
     const uint32_t set = blockIdx.y;
     const BaseView<F> bases = views.v[set];
-    items += set * L.items; partials += set * L.partials; buckets += set * L.buckets;
+    items += set * L.items; partials += set * L.partials; buckets += set * L.buckets;          // (out29: one set per launch, no offset)
     const uint32_t n_items = counters[2 * set], t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (uint32_t base = blockIdx.x * 4; base < n_items; base += gridDim.x * 4) {      // uniform trip count per workgroup
         uint32_t it = base + wv;
@@ -615,14 +639,14 @@ __global__ __launch_bounds__(256) void k_heavy_parts(const ViewSet<F> views, con
         sh[t] = acc;
         __syncthreads();
         lds_tree_reduce<F>(sh + wv * 64, 64, lane, 64, [] { __syncthreads(); });      // the four wavefronts run their trees in step
-        if (lane == 0 && it < n_items) { if (items[it].single) buckets[items[it].gb] = sh[t].normalized(); else partials[it] = sh[t].normalized(); }
+        if (lane == 0 && it < n_items) { if (items[it].single) put_bucket<F>(buckets, items[it].gb, sh[t].normalized(), out29); else partials[it] = sh[t].normalized(); }
         __syncthreads();
     }
 }
 
 // one workgroup per heavy bucket: strided sum of its parts' partials, LDS tree, write the bucket
 template <class F>
-__global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, const uint32_t *counters, const XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L) {
+__global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, const uint32_t *counters, const XYZZ<F> *partials, XYZZ<F> *buckets, SetLayout L, int out29, int resume) {
     extern __shared__ unsigned char red_smem[];
     LdsPoint<F> *sh = reinterpret_cast<LdsPoint<F> *>(red_smem);
     const uint32_t set = blockIdx.y;
@@ -632,10 +656,13 @@ __global__ __launch_bounds__(256) void k_heavy_merge(const HeavyBucket *heavy, c
         HeavyBucket h = heavy[hb];
         XYZZ<F> acc = XYZZ<F>::inf();
         for (uint32_t p = t; p < h.nparts; p += 256) acc.add(partials[h.first_item + p]);
+        if constexpr (sizeof(F) == sizeof(Fq)) {
+            if (resume && out29 && t == 255) acc.add(bucket29_to_xyzz(load_bucket29_raw(reinterpret_cast<const Bucket29 *>(buckets) + h.gb)));   // the earlier pieces' sum
+        }
         sh[t] = acc;
         __syncthreads();
         lds_tree_reduce<F>(sh, 256, t, 256, [] { __syncthreads(); });
-        if (t == 0) buckets[h.gb] = sh[0].normalized();
+        if (t == 0) put_bucket<F>(buckets, h.gb, sh[0].normalized(), out29);
         __syncthreads();
     }
 }
@@ -697,31 +724,40 @@ __global__ __launch_bounds__(RedGeom<F>::THREADS) void k_bucket_reduce(const XYZ
 //      products at two wavefronts per SIMD, where a 29-bit product takes 930 cycles against 1293.  Buckets arrive as the accumulation wrote
 //      them (canonical XYZZ<Fq>) and are converted on load, one coordinate per lane of the quad; the two chunk results leave as XYZZ<Fq>.
 struct alignas(16) LdsPoint29 { XYZZ29q p; uint32_t pad[4]; };
-ZK_D XYZZ29q load_bucket29(const XYZZ<Fq> *X, uint32_t i, uint32_t B, uint32_t q) {
+template <bool IN29> ZK_D XYZZ29q load_bucket29(const void *X_, uint32_t i, uint32_t B, uint32_t q) {
     if (i >= B) return XYZZ29q::inf();
-    const XYZZ<Fq> b = X[i];
-    if (b.is_inf()) return XYZZ29q::inf();
-    return quad_load29(b.x, b.y, b.zz, b.zzz, q);
+    if constexpr (IN29) {                                                        // as the accumulation left it: no conversion, every lane of the quad reads the record
+        const Bucket29 b = load_bucket29_raw(reinterpret_cast<const Bucket29 *>(X_) + i);
+        XYZZ29q r;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { r.x.v[j] = b.x[j]; r.y.v[j] = b.y[j]; r.zz.v[j] = b.zz[j]; r.zzz.v[j] = b.zzz[j]; }
+        return r;
+    } else {
+        const XYZZ<Fq> b = reinterpret_cast<const XYZZ<Fq> *>(X_)[i];
+        if (b.is_inf()) return XYZZ29q::inf();
+        return quad_load29(b.x, b.y, b.zz, b.zzz, q);
+    }
 }
 ZK_D XYZZ<Fq> store_point29(const XYZZ29q &p) {
     if (p.is_inf()) return XYZZ<Fq>::inf().normalized();
     return {f29::from29(p.x), f29::from29(p.y), f29::from29(p.zz), f29::from29(p.zzz)};
 }
-template <int RED_L_LOG>
-__global__ __launch_bounds__(RedGeom<Fq>::THREADS) void k_bucket_reduce29(const XYZZ<Fq> *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
+template <int RED_L_LOG, bool IN29>
+__global__ __launch_bounds__(RedGeom<Fq>::THREADS) void k_bucket_reduce29(const void *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
                                                                           size_t in_set_stride, size_t out_set_stride) {
     constexpr int RED_LANES = RedGeom<Fq>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
     LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * RED_LANES points
     const uint32_t t = threadIdx.x >> 2, q = threadIdx.x & 3;
     const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
-    const XYZZ<Fq> *X = buckets + blockIdx.y * in_set_stride + (size_t)w * B;
+    const size_t elem = IN29 ? sizeof(Bucket29) : sizeof(XYZZ<Fq>);
+    const void *X = reinterpret_cast<const char *>(buckets) + (blockIdx.y * in_set_stride + (size_t)w * B) * elem;
     out += blockIdx.y * out_set_stride;
     const uint32_t base = ch * RED_CHUNK + t * RED_L;
     XYZZ29q run = XYZZ29q::inf(), T0 = XYZZ29q::inf();
-    XYZZ29q cur = load_bucket29(X, base + RED_L - 1, B, q);
+    XYZZ29q cur = load_bucket29<IN29>(X, base + RED_L - 1, B, q);
     for (int j = RED_L - 1; j >= 1; --j) {
-        const XYZZ29q nxt = load_bucket29(X, base + j - 1, B, q);
+        const XYZZ29q nxt = load_bucket29<IN29>(X, base + j - 1, B, q);
         xyzz29_add_quad(run, cur, q);
         xyzz29_add_quad(T0, run, q);
         cur = nxt;
@@ -939,8 +975,13 @@ struct MsmJob {
     // leave most of the chip idle: fork after everything queued before (the previous launch's accumulation still reads the records), join before the accumulation
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool converted_aside = false;
     bool one_pass_sort = false;        // the caller knows the digits are skewed (a prover's 0/1 witness): skip the two-pass sort's attempt
+    // piece-wise jobs (msm_g1_host_scalars): `resume` — this launch's accumulation continues the buckets of the launch before it;
+    // `defer_reduce` — more pieces follow: no reduction, nothing copied back; `c_fixed` — every piece uses the whole job's window size
+    bool resume = false, defer_reduce = false; bool last_out29 = false;
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     bool empty = false;
+    // bases resident, scalars in host memory (msm_g1_host_scalars): device copy of the scalars, the copy stream and one event per piece
+    DevBuf hs_scalars; hipStream_t copy = nullptr; hipEvent_t ev_piece[8] = {nullptr};
     std::mutex mu;
 };
 
@@ -964,7 +1005,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 2;
     if (gr.heavy_items.reserve(ns * max_items * sizeof(HeavyItem)) || gr.heavy_buckets.reserve(ns * max_heavy * sizeof(HeavyBucket)) ||
         gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
-        gr.buckets.reserve(ns * total_buckets * sizeof(XYZZ<F>)) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
+        gr.buckets.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
         (gr.table && gr.folded.reserve(ns * (size_t)g.B * sizeof(XYZZ<F>))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
     // (gr.heavy_counters: cleared by the job's k_digits)
     XYZZ<F> *buckets = gr.buckets.as<XYZZ<F>>();
@@ -995,6 +1036,12 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
             use29 = true; rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
         }
     }
+    static const bool red32_env = getenv("ZKG_REDUCE_32") != nullptr;
+    // plain G1 set on the 29-bit kernels: the buckets stay 29-bit records from the accumulation to the reduction
+    const bool out29 = use29 && stride29 == 0 && !gr.table && !red32_env;
+    const int resume = job->resume ? 1 : 0;
+    if (resume && !(out29 && job->last_out29)) { set_error("msm: a piece can only continue 29-bit buckets"); return ZKG_ERROR; }
+    job->last_out29 = out29;
     if (time_it) g_dominant_timer.begin(s);
     bool done_ba = false;
     if constexpr (sizeof(F) == sizeof(Fq)) {
@@ -1003,7 +1050,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         const char *e_ba = getenv("ZKG_ACCUM_BA"), *e_k = getenv("ZKG_BA_K");
         const int ba_levels = e_ba ? std::max(0, std::min((int)ba::MAX_LEVELS, atoi(e_ba))) : 0;
         const int ba_k = e_k ? std::max(2, std::min(32, atoi(e_k) & ~1)) : 16;
-        if (use29 && stride29 == 0 && ba_levels > 0 && n_entries_max >= 4096) {
+        if (use29 && out29 && !resume && ba_levels > 0 && n_entries_max >= 4096) {
             const int R = ba_levels, K = ba_k;
             const size_t per_wg = (size_t)ba::THREADS * K, words_start = n_entries_max / 32 + 2;
             size_t stride[ba::MAX_LEVELS + 1] = {0}, plane_words = 0, grid1 = 0;
@@ -1032,7 +1079,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                 }
             }
             hipLaunchKernelGGL(k_bucket_accum_ba, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, job->sorted.as<uint32_t>(), pl, R, job->offsets.as<uint32_t>(),
-                               job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(),
+                               job->order.as<uint32_t>(), lanes, reinterpret_cast<Bucket29 *>(buckets), gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(),
                                gr.heavy_counters.as<uint32_t>(), L);
             done_ba = true;
         }
@@ -1040,14 +1087,13 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if (done_ba) {}
     else if constexpr (sizeof(F) == sizeof(Fq)) {
         static const int waves29 = getenv("ZKG_ACC29_WAVES") ? atoi(getenv("ZKG_ACC29_WAVES")) : 2;               // tuning aid
-        if (use29 && waves29 == 3)
-            hipLaunchKernelGGL(k_bucket_accum29<3>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
-                               job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(),
-                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
-        else if (use29)
-            hipLaunchKernelGGL(k_bucket_accum29<2>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
-                               job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, reinterpret_cast<XYZZ<Fq> *>(buckets), gr.heavy_items.as<HeavyItem>(),
-                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
+        auto launch29 = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
+                               job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, (void *)buckets, gr.heavy_items.as<HeavyItem>(),
+                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L, resume);
+        };
+        if (use29 && waves29 == 3) { if (out29) launch29(k_bucket_accum29<3, true>); else launch29(k_bucket_accum29<3, false>); }
+        else if (use29) { if (out29) launch29(k_bucket_accum29<2, true>); else launch29(k_bucket_accum29<2, false>); }
     }
     if (use29 || done_ba) {}
     else if (plain)
@@ -1060,9 +1106,13 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                            gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     if (time_it) g_dominant_timer.end(s);
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
-                       views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
+                       views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L, (int)out29);
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
-                       gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L);
+                       gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L, (int)out29, resume);
+    if (job->defer_reduce) {                                                    // a piece of a larger job: its buckets wait for the next piece
+        if (hipGetLastError() != hipSuccess) { set_error("msm kernel launch failed"); return ZKG_ERROR; }
+        return ZKG_OK;
+    }
     const XYZZ<F> *red_in = buckets; size_t in_stride = L.buckets;
     if (gr.table) {
         uint32_t slots = 1; while (slots < g.W && slots < 32) slots <<= 1;                // window slots per workgroup: W rounded up to a power of two (<= 32)
@@ -1073,14 +1123,20 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     }
     bool reduce29 = false;
     if constexpr (sizeof(F) == sizeof(Fq)) {
-        static const bool red32 = getenv("ZKG_REDUCE_32") != nullptr;                                     // A/B switch
-        reduce29 = !accum32 && !red32;
+        reduce29 = !accum32 && !red32_env;                                                                 // (ZKG_REDUCE_32: A/B switch)
         if (reduce29) {
             const size_t lds = 2 * RG::LANES * sizeof(LdsPoint29);
-            const XYZZ<Fq> *rin = reinterpret_cast<const XYZZ<Fq> *>(red_in); XYZZ<Fq> *rout = reinterpret_cast<XYZZ<Fq> *>(gr.red_out.p);
-            if (red_l_log == RED_L_LOG_LARGE) hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_LARGE>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
-            else if (red_l_log == RED_L_LOG_SMALL) hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_SMALL>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
-            else hipLaunchKernelGGL(k_bucket_reduce29<RED_L_LOG_TINY>, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out);
+            const void *rin = red_in; XYZZ<Fq> *rout = reinterpret_cast<XYZZ<Fq> *>(gr.red_out.p);
+            auto launch_red = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
+            if (out29) {
+                if (red_l_log == RED_L_LOG_LARGE) launch_red(k_bucket_reduce29<RED_L_LOG_LARGE, true>);
+                else if (red_l_log == RED_L_LOG_SMALL) launch_red(k_bucket_reduce29<RED_L_LOG_SMALL, true>);
+                else launch_red(k_bucket_reduce29<RED_L_LOG_TINY, true>);
+            } else {
+                if (red_l_log == RED_L_LOG_LARGE) launch_red(k_bucket_reduce29<RED_L_LOG_LARGE, false>);
+                else if (red_l_log == RED_L_LOG_SMALL) launch_red(k_bucket_reduce29<RED_L_LOG_SMALL, false>);
+                else launch_red(k_bucket_reduce29<RED_L_LOG_TINY, false>);
+            }
         }
     }
     if (reduce29) {}
@@ -1342,6 +1398,58 @@ int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2
     return ZKG_OK;
 }
 
+// Bases resident, scalars in HOST memory: SURVEY.md section 8(d)'s step ("wall clock around the call incl. H2D of scalars; bases resident") as
+// one entry point.  The upload is 32 B x n over PCIe (0.6 ms at 2^20 points) against 1.9 ms of work that cannot start on a scalar it has not
+// seen — so the job is cut by POINTS into pieces (1/8, 1/8, 1/4, 1/2 of them: a small first piece starts the chip early, and every later
+// piece's upload is shorter than the work of the piece before it), each piece sorted and accumulated as it lands, all pieces into ONE set of
+// buckets (k_bucket_accum29's `resume`: a lane picks its bucket's 29-bit accumulator up where the last piece left it), and one reduction at
+// the end.  Same point as msm_g1 on the uploaded vector: the buckets hold the same sums, whatever the order of the additions.
+int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
+    if (n >= ((size_t)1 << 28)) { set_error("msm: at most 2^28 - 1 points per call"); return ZKG_ERROR; }
+    if (!n) { *out = G1::inf(); return ZKG_OK; }
+    static const int max_pieces = getenv("ZKG_MSM_PIECES") ? std::max(1, std::min(8, atoi(getenv("ZKG_MSM_PIECES")))) : 4;        // tuning aid (1: one upload, one launch)
+    static const bool no29 = getenv("ZKG_ACCUM_32") != nullptr || getenv("ZKG_REDUCE_32") != nullptr;
+    const bool pieces = max_pieces > 1 && !no29 && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 23);
+    if (!pieces) {                                                              // small, huge or switched off: one upload, then the resident path
+        ScopedDevBuf tmp;
+        if (tmp.reserve(n * 32)) return ZKG_ERROR;
+        ZK_HIP(hipMemcpyAsync(tmp.p, h_scalars, n * 32, hipMemcpyHostToDevice, s));
+        return msm_g1(d_bases, tmp.as<uint32_t>(), n, mont, out, s, false);     // (returns after the stream has drained: tmp may go)
+    }
+    MsmJob &J = g_default_job;
+    std::lock_guard<std::mutex> lk(J.mu);
+    if (J.hs_scalars.reserve(n * 32)) return ZKG_ERROR;
+    if (!J.copy) {
+        if (hipStreamCreateWithFlags(&J.copy, hipStreamNonBlocking) != hipSuccess) { J.copy = nullptr; set_error("msm: copy stream"); return ZKG_ERROR; }
+        for (auto &e : J.ev_piece) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("msm: event"); return ZKG_ERROR; }
+    }
+    uint32_t *d_sc = J.hs_scalars.as<uint32_t>();
+    J.stream = s; J.w0 = 0; J.ws = 1; J.one_pass_sort = false;
+    MsmBases set; set.p = d_bases;
+    // piece boundaries: halves from the top, the lowest one split once more -> n/8, n/8, n/4, n/2 for four pieces
+    size_t cut[9]; int P = max_pieces;
+    cut[P] = n;
+    for (int k = P - 1; k >= 1; --k) cut[k] = (cut[k + 1] / 2) & ~(size_t)255;
+    cut[0] = 0;
+    for (int k = 0; k < P; ++k) {
+        ZK_HIP(hipMemcpyAsync(d_sc + 8 * cut[k], h_scalars + 8 * cut[k], (cut[k + 1] - cut[k]) * 32, hipMemcpyHostToDevice, J.copy));
+        ZK_HIP(hipEventRecord(J.ev_piece[k], J.copy));
+    }
+    const int saved_hint = J.window_hint;
+    J.window_hint = (int)pick_geom(n, saved_hint).c;                          // every piece under the whole job's window size
+    int rc = ZKG_OK;
+    for (int k = 0; k < P && rc == ZKG_OK; ++k) {
+        if (cut[k + 1] == cut[k]) continue;
+        MsmBases piece = set; piece.p = reinterpret_cast<const char *>(d_bases) + cut[k] * sizeof(G1Affine);
+        J.resume = k > 0; J.defer_reduce = k + 1 < P;
+        if (hipStreamWaitEvent(s, J.ev_piece[k], 0) != hipSuccess) { rc = ZKG_ERROR; break; }
+        rc = msm_job_launch(&J, &piece, 1, d_sc + 8 * cut[k], cut[k + 1] - cut[k], mont, nullptr);
+    }
+    J.resume = false; J.defer_reduce = false; J.window_hint = saved_hint;
+    if (rc != ZKG_OK) { (void)hipStreamSynchronize(J.copy); (void)hipStreamSynchronize(s); return ZKG_ERROR; }
+    return msm_job_finish(&J, out, nullptr);
+}
+
 int msm_g1(const G1Affine *d_bases, const uint32_t *d_scalars, size_t n, bool mont, G1 *out, hipStream_t s, bool mostly_bits) {
     return msm_shared(&d_bases, 1, nullptr, d_scalars, n, mont, out, nullptr, s, 0, 1, mostly_bits);
 }
@@ -1535,6 +1643,9 @@ void msm_release_all() {
     for (DevBuf *b : {&j.digits, &j.hist, &j.counts, &j.offsets, &j.scan_sums, &j.class_hist, &j.order, &j.sorted, &j.rx_tmp, &j.rx_meta}) b->release();
     for (auto &gr : j.group) gr.release();
     if (j.aux) { (void)hipStreamSynchronize(j.aux); (void)hipStreamDestroy(j.aux); j.aux = nullptr; }      // (a later zkg_init may pick another device)
+    j.hs_scalars.release();
+    if (j.copy) { (void)hipStreamSynchronize(j.copy); (void)hipStreamDestroy(j.copy); j.copy = nullptr; }
+    for (auto &e : j.ev_piece) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (j.ev_fork) { (void)hipEventDestroy(j.ev_fork); j.ev_fork = nullptr; }
     if (j.ev_join) { (void)hipEventDestroy(j.ev_join); j.ev_join = nullptr; }
 }
