@@ -339,6 +339,7 @@ def main():
                          "and owns every N-th Pippenger window; SURVEY.md section 8e's variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT and Groth16-prove legs (reported under 'extras')")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline steps (no resident-scalars legs): what tools/pmc_collect.sh profiles, so that every launch it sees belongs to a headline step")
     ap.add_argument("--config5-reference", action="store_true", help="also time the whole 2^26-point MSM of BASELINE configs[4] on ONE GPU (6 GB of inputs; the strong-scaling reference for the 8 x 2^23 run)")
     ap.add_argument("--no-northstar", action="store_true", help="skip the second prove leg (37 payloads, m = 2^20: the north star's 2^20-constraint case)")
     ap.add_argument("--prove-logm", type=int, default=18, help="log2 of the evaluation domain of the prove leg: 18 = 8 payloads (BASELINE configs[3]), 20 = 37 payloads (the north star's 2^20-constraint case)")
@@ -385,12 +386,24 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     from zklaim_amd import dist as zdist
 
-    def step():
+    # The timed step is SURVEY.md section 8(d)'s / BASELINE.md's: wall clock around the C-ABI call INCLUDING the upload of the scalars (32 B x
+    # points from pinned host memory), bases resident, result back on the host.  zkg_msm_g1_host_scalars cuts the job into pieces whose
+    # uploads run under the work of the pieces before them.  The resident-scalars figure (zkg_msm_g1_dev) is reported beside it.
+    h_sc = torch.from_numpy(sc.view(np.int64)).pin_memory()
+
+    def step_resident():
         if by_windows:
             w0, ws = zdist.window_shard(world, rank)
             part = zkg.msm_g1_windows_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, w0, ws, stream=stream)
         else:
             part = zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n, stream=stream)   # normalised partial (host)
+        return zdist.combine_partials_g1(part, device="cuda") if use_dist else part
+
+    def step():
+        if by_windows:
+            d_sc.copy_(h_sc, non_blocking=True)              # the window-sharded variant has no piece-wise form: upload, then the resident call
+            return step_resident()
+        part = zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_sc.data_ptr(), n, stream=stream)
         return zdist.combine_partials_g1(part, device="cuda") if use_dist else part
 
     def fence():
@@ -415,22 +428,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches = zkg.timing_dominant_ms()
+    kern_ms = kern_ms * launches / max(1, args.steps)                        # the accumulation's launches of one step (one per piece) added up
     same_everywhere = all_ranks_same(torch, dist, result, use_dist)          # outside the timed region
-    # SURVEY.md section 8(d)'s other form of the same step: the scalars start in (pinned) HOST memory and their 32 B x n upload is inside the timed
-    # call, bases resident.  Reported next to `value`, never as `value`.
-    h2d = None
-    if world == 1:
-        h_sc = torch.from_numpy(sc.view(np.int64)).pin_memory()
-        d_sc2 = torch.empty_like(d_sc)
-        def step_h2d():
-            d_sc2.copy_(h_sc, non_blocking=True)
-            return zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n, stream=stream)
-        step_h2d(); step_h2d()
+    # the same step with the scalars already in HBM (rounds 1-3's headline), and with ONE upload followed by the resident call (what the
+    # piece-wise entry point replaces) — reported beside `value`, same result required
+    resident = None
+    if world == 1 and not args.headline_only:
+        step_resident(); step_resident()
         each = []
         for _ in range(args.steps):
-            t_s = time.perf_counter(); r2 = step_h2d(); each.append(time.perf_counter() - t_s)
-        h2d = {"ms_per_step": stats_ms(each), "GBps_algorithmic_median": round(BYTES_PER_POINT * n / float(np.median(each)) / 1e9, 3),
-               "same_result": bool(np.array_equal(r2, result)), "what": "scalar H2D (32 B x points from pinned host memory) + MSM + result D2H inside the timed call; bases resident"}
+            t_s = time.perf_counter(); r2 = step_resident(); each.append(time.perf_counter() - t_s)
+        d_sc2 = torch.empty_like(d_sc)
+        def step_plain_upload():
+            d_sc2.copy_(h_sc, non_blocking=True)
+            return zkg.msm_g1_dev(d_bases.data_ptr(), d_sc2.data_ptr(), n, stream=stream)
+        step_plain_upload()
+        each_u = []
+        for _ in range(args.steps):
+            t_s = time.perf_counter(); r3 = step_plain_upload(); each_u.append(time.perf_counter() - t_s)
+        resident = {"ms_per_step": stats_ms(each), "GBps_algorithmic_mean": round(BYTES_PER_POINT * n / float(np.mean(each)) / 1e9, 3),
+                    "GBps_algorithmic_median": round(BYTES_PER_POINT * n / float(np.median(each)) / 1e9, 3),
+                    "same_result": bool(np.array_equal(r2, result)), "what": "zkg_msm_g1_dev: bases AND scalars resident in HBM when the timed call starts (the headline of rounds 1-3)",
+                    "one_upload_then_resident_call": {"ms_per_step": stats_ms(each_u), "GBps_algorithmic_median": round(BYTES_PER_POINT * n / float(np.median(each_u)) / 1e9, 3),
+                                                      "same_result": bool(np.array_equal(r3, result))}}
 
     total_points = n if by_windows else n * world
     n = n // world if by_windows else n            # per-rank share of the points, for the per-launch algorithmic bytes below
@@ -441,14 +461,16 @@ def main():
     line = {
         "metric": "Groth16 proofs/sec (zklaim gadget, alt_bn128) + G1 MSM GB/s vs HBM roofline", "metric_component": "G1 MSM GB/s (value, unit); Groth16 proofs/sec of the zklaim gadget in extras.groth16_prove and proofs_per_sec", "value": round(value, 3), "unit": "GB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_stats": stats_ms(per_step),
-        "incl_scalar_h2d": h2d, "all_ranks_same_result": same_everywhere, "higher_is_better": True,
+        "timed_region": "SURVEY.md section 8(d): wall clock around the C-ABI call (zkg_msm_g1_host_scalars) incl. the upload of the scalars from pinned host memory and the result's return; bases resident",
+        "scalars_resident": resident, "all_ranks_same_result": same_everywhere, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs, Montgomery (254-bit Fq/Fr: 9 x 29-bit in the accumulation, reduction and NTT kernels, 8 x 32-bit elsewhere)", "data": "synthetic",
         "config": {"workload": f"2^{args.logn}-point alt_bn128 G1 Pippenger MSM per GPU, random scalars/bases (BASELINE configs[1])",
                    "points_per_gpu": n, "total_points": total_points, "arch": arch, "compute_units": cus,
                    "sharding": ("windows sharded per rank (every rank holds all points); " if by_windows else "points sharded per rank; ") + "all-gather of normalised partial points + EC add" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_bucket_accum29", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                     "kernel_ms": round(kern_ms, 4), "launches": launches,
+                     "kernel_ms": round(kern_ms, 4), "launches": launches, "launches_per_step": round(launches / max(1, args.steps), 2),
+                     "kernel_ms_note": "the accumulation's launches of ONE step added up (the piece-wise step launches it once per piece), HIP events on the launch stream",
                      "note": "integer-VALU-bound kernel (10 Montgomery products of 9 x 29-bit limbs per 96 input bytes and window); see DESIGN.md"},
     }
     if kern_ms > 0:
@@ -471,10 +493,10 @@ def main():
     if args.logn == LOGN and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            line["roofline"]["algorithmic_bytes_per_launch"] = BYTES_PER_POINT * n
+            line["roofline"]["algorithmic_bytes_per_step"] = BYTES_PER_POINT * n
             if pmc.get("source_sha16") == kernel_source_sha16():
-                line["roofline"]["traffic"] = pmc.get("dominant_hbm_bytes_per_launch")
-                line["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x gather calibration + WRITE_SIZE, separate --pmc passes)"
+                line["roofline"]["traffic"] = pmc.get("dominant_hbm_bytes_per_step")
+                line["roofline"]["traffic_unit"] = "bytes per step, all of the accumulation's launches of a step (FETCH_SIZE x gather calibration + WRITE_SIZE, separate --pmc passes)"
                 line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (collected on these kernel sources: sha16 " + pmc["source_sha16"] + ")"
             else:
                 line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json was collected on other kernel sources; not reported (re-run tools/pmc_collect.sh)"

@@ -13,6 +13,9 @@ def load(pat):
     return list(csv.DictReader(open(glob.glob(pat)[0])))
 
 
+CALLS = 4          # tools/pmc_collect.sh runs bench.py --headline-only --steps 3 --warmup 1: every launch belongs to one of these 4 steps
+
+
 def per_kernel(rows):
     agg = collections.defaultdict(list)
     for r in rows:
@@ -30,7 +33,7 @@ stream_factor = known_stream / calib_f["k_stream16"][0]
 store_factor = known_stream / calib_w["k_store16"][0]
 bf = per_kernel(load(f"{src}/bench_FETCH_SIZE/*/*counter_collection.csv"))
 bw = per_kernel(load(f"{src}/bench_WRITE_SIZE/*/*counter_collection.csv"))
-out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1",
+out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-cpu-baseline --no-extras --headline-only --steps 3 --warmup 1",
        "calibration": {"gather64_true_over_reported": round(gather_factor, 4), "stream16_true_over_reported": round(stream_factor, 4),
                        "store16_true_over_reported": round(store_factor, 4),
                        "note": "FETCH_SIZE of k_bucket_accum29 is corrected with the 64-B gather factor (its reads are 80-B record gathers, five 16-B loads per lane, plus a 4-B/lane index stream)"},
@@ -46,6 +49,8 @@ if acc:
     e["hbm_bytes_corrected"] = int(e["fetch_bytes_raw"] * gather_factor + e["write_bytes_raw"] * store_factor)
     out["dominant_kernel"] = k
     out["dominant_hbm_bytes_per_launch"] = e["hbm_bytes_corrected"]
+    out["dominant_launches_per_step"] = e["launches"] / CALLS
+    out["dominant_hbm_bytes_per_step"] = int(e["hbm_bytes_corrected"] * e["launches"] / CALLS)
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bench import kernel_source_sha16

@@ -978,6 +978,8 @@ struct MsmJob {
     // piece-wise jobs (msm_g1_host_scalars): `resume` — this launch's accumulation continues the buckets of the launch before it;
     // `defer_reduce` — more pieces follow: no reduction, nothing copied back; `c_fixed` — every piece uses the whole job's window size
     bool resume = false, defer_reduce = false; bool last_out29 = false;
+    // a second job that alternates with this one over the pieces of one multi-exponentiation accumulates into THIS job's buckets
+    MsmJob *bucket_owner = nullptr; hipEvent_t ev_accum_wait = nullptr;    // ev_accum_wait: the other job's accumulation (same buckets) that must be through first
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     bool empty = false;
     // bases resident, scalars in host memory (msm_g1_host_scalars): device copy of the scalars, the copy stream and one event per piece
@@ -1002,13 +1004,14 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     const int red_l_log = force_l ? atoi(force_l) : red_buckets >= RED_LARGE_BUCKETS ? RED_L_LOG_LARGE : red_buckets > RED_SMALL_BUCKETS ? RED_L_LOG_SMALL : RED_L_LOG_TINY;
     gr.chunk_log = RG::LANES_LOG + red_l_log;
     gr.cpw = (g.B + (1u << gr.chunk_log) - 1) >> gr.chunk_log; gr.nred = (size_t)gr.red_windows * gr.cpw;
+    DevBuf &bucket_buf = job->bucket_owner ? job->bucket_owner->group[sizeof(F) != sizeof(Fq) ? 1 : 0].buckets : gr.buckets;
     SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 2;
     if (gr.heavy_items.reserve(ns * max_items * sizeof(HeavyItem)) || gr.heavy_buckets.reserve(ns * max_heavy * sizeof(HeavyBucket)) ||
         gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
-        gr.buckets.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
+        bucket_buf.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
         (gr.table && gr.folded.reserve(ns * (size_t)g.B * sizeof(XYZZ<F>))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
     // (gr.heavy_counters: cleared by the job's k_digits)
-    XYZZ<F> *buckets = gr.buckets.as<XYZZ<F>>();
+    XYZZ<F> *buckets = bucket_buf.as<XYZZ<F>>();
     ViewSet<F> views;
     for (unsigned i = 0; i < (unsigned)MSM_MAX_SETS; ++i) {
         const MsmBases &b = sets[i < ns ? i : 0];
@@ -1040,8 +1043,10 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     // plain G1 set on the 29-bit kernels: the buckets stay 29-bit records from the accumulation to the reduction
     const bool out29 = use29 && stride29 == 0 && !gr.table && !red32_env;
     const int resume = job->resume ? 1 : 0;
-    if (resume && !(out29 && job->last_out29)) { set_error("msm: a piece can only continue 29-bit buckets"); return ZKG_ERROR; }
-    job->last_out29 = out29;
+    MsmJob *owner = job->bucket_owner ? job->bucket_owner : job;                // (whose buckets these are)
+    if (resume && !(out29 && owner->last_out29)) { set_error("msm: a piece can only continue 29-bit buckets"); return ZKG_ERROR; }
+    owner->last_out29 = out29;
+    if (job->ev_accum_wait) ZK_HIP(hipStreamWaitEvent(s, job->ev_accum_wait, 0));      // the sort above ran beside it; the buckets are shared
     if (time_it) g_dominant_timer.begin(s);
     bool done_ba = false;
     if constexpr (sizeof(F) == sizeof(Fq)) {
@@ -1298,6 +1303,7 @@ void msm_job_destroy(MsmJob *j) {
 }
 
 static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex); only it feeds the kernel timer
+static MsmJob g_piece_job;            // msm_g1_host_scalars: odd pieces sort here, on a stream of their own, beside the even pieces' accumulation (under g_default_job's mutex)
 
 // enqueue: one digit sort of the scalars (element d_gather[i] of d_scalars when a gather list is given), then one accumulate + reduce
 // per base set
@@ -1348,7 +1354,7 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
     lap("sort enqueued");
     const bool timed_field_g2 = job->group[0].nsets == 0;                       // the kernel timer follows the first G1 launch (G2 when there is no G1 set)
     if (job->group[1].nsets && launch_accumulate<Fq2>(job, job->group[1], by_field[1], d_gather, job == &g_default_job && timed_field_g2)) return fail();   // G2 first: the longer chains
-    if (job->group[0].nsets && launch_accumulate<Fq>(job, job->group[0], by_field[0], d_gather, job == &g_default_job)) return fail();
+    if (job->group[0].nsets && launch_accumulate<Fq>(job, job->group[0], by_field[0], d_gather, job == &g_default_job || job == &g_piece_job)) return fail();
     lap("accum enqueued");
     return ZKG_OK;
 }
@@ -1400,17 +1406,17 @@ int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2
 
 // Bases resident, scalars in HOST memory: SURVEY.md section 8(d)'s step ("wall clock around the call incl. H2D of scalars; bases resident") as
 // one entry point.  The upload is 32 B x n over PCIe (0.6 ms at 2^20 points) against 1.9 ms of work that cannot start on a scalar it has not
-// seen — so the job is cut by POINTS into pieces (1/8, 1/8, 1/4, 1/2 of them: a small first piece starts the chip early, and every later
+// seen — so the job is cut by POINTS into pieces (1/4, 1/4, 1/2 of them: a small first piece starts the chip early, and every later
 // piece's upload is shorter than the work of the piece before it), each piece sorted and accumulated as it lands, all pieces into ONE set of
 // buckets (k_bucket_accum29's `resume`: a lane picks its bucket's 29-bit accumulator up where the last piece left it), and one reduction at
 // the end.  Same point as msm_g1 on the uploaded vector: the buckets hold the same sums, whatever the order of the additions.
 int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
     if (n >= ((size_t)1 << 28)) { set_error("msm: at most 2^28 - 1 points per call"); return ZKG_ERROR; }
     if (!n) { *out = G1::inf(); return ZKG_OK; }
-    static const int max_pieces = getenv("ZKG_MSM_PIECES") ? std::max(1, std::min(8, atoi(getenv("ZKG_MSM_PIECES")))) : 4;        // tuning aid (1: one upload, one launch)
+    static const int max_pieces = getenv("ZKG_MSM_PIECES") ? std::max(1, std::min(8, atoi(getenv("ZKG_MSM_PIECES")))) : 3;        // tuning aid (1: one upload, one launch); measured 2 / 3 / 4 / 5 pieces: 2.25 / 2.19 / 2.27 / 2.41 ms at 2^20 points
     static const bool no29 = getenv("ZKG_ACCUM_32") != nullptr || getenv("ZKG_REDUCE_32") != nullptr;
     const bool pieces = max_pieces > 1 && !no29 && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 23);
-    if (!pieces) {                                                              // small, huge or switched off: one upload, then the resident path
+    if (n > ((size_t)1 << 23)) {                                                // huge: one upload, then the resident path's own 2^23-point pieces
         ScopedDevBuf tmp;
         if (tmp.reserve(n * 32)) return ZKG_ERROR;
         ZK_HIP(hipMemcpyAsync(tmp.p, h_scalars, n * 32, hipMemcpyHostToDevice, s));
@@ -1426,7 +1432,12 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
     uint32_t *d_sc = J.hs_scalars.as<uint32_t>();
     J.stream = s; J.w0 = 0; J.ws = 1; J.one_pass_sort = false;
     MsmBases set; set.p = d_bases;
-    // piece boundaries: halves from the top, the lowest one split once more -> n/8, n/8, n/4, n/2 for four pieces
+    if (!pieces) {                                                              // small or switched off: one upload in stream order, one launch
+        ZK_HIP(hipMemcpyAsync(d_sc, h_scalars, n * 32, hipMemcpyHostToDevice, s));
+        if (msm_job_launch(&J, &set, 1, d_sc, n, mont, nullptr)) return ZKG_ERROR;
+        return msm_job_finish(&J, out, nullptr);
+    }
+    // piece boundaries: halves from the top, the lowest one split once more -> n/4, n/4, n/2 for three pieces
     size_t cut[9]; int P = max_pieces;
     cut[P] = n;
     for (int k = P - 1; k >= 1; --k) cut[k] = (cut[k + 1] / 2) & ~(size_t)255;
@@ -1435,18 +1446,42 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
         ZK_HIP(hipMemcpyAsync(d_sc + 8 * cut[k], h_scalars + 8 * cut[k], (cut[k + 1] - cut[k]) * 32, hipMemcpyHostToDevice, J.copy));
         ZK_HIP(hipEventRecord(J.ev_piece[k], J.copy));
     }
-    const int saved_hint = J.window_hint;
-    J.window_hint = (int)pick_geom(n, saved_hint).c;                          // every piece under the whole job's window size
-    int rc = ZKG_OK;
-    for (int k = 0; k < P && rc == ZKG_OK; ++k) {
-        if (cut[k + 1] == cut[k]) continue;
-        MsmBases piece = set; piece.p = reinterpret_cast<const char *>(d_bases) + cut[k] * sizeof(G1Affine);
-        J.resume = k > 0; J.defer_reduce = k + 1 < P;
-        if (hipStreamWaitEvent(s, J.ev_piece[k], 0) != hipSuccess) { rc = ZKG_ERROR; break; }
-        rc = msm_job_launch(&J, &piece, 1, d_sc + 8 * cut[k], cut[k + 1] - cut[k], mont, nullptr);
+    // Pieces alternate between two jobs (two streams, two sets of sort buffers, ONE set of buckets): the digit sort of piece k + 1 runs
+    // beside the accumulation of piece k — its small dependent launches and single-workgroup scans cost the chip little there, and a
+    // third of a step when they stand alone.  The last piece is the caller's job and stream (it carries the reduction and the result).
+    static const bool two_jobs = getenv("ZKG_MSM_PIECES_ONE_STREAM") == nullptr;                          // A/B switch
+    MsmJob &K = g_piece_job;
+    if (two_jobs && !K.stream) {
+        if (hipStreamCreateWithFlags(&K.stream, hipStreamNonBlocking) != hipSuccess) { K.stream = nullptr; set_error("msm: piece stream"); return ZKG_ERROR; }
+        K.own_stream = true;
+        if (hipEventCreateWithFlags(&K.ev_accum_wait, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&J.ev_accum_wait, hipEventDisableTiming) != hipSuccess) { set_error("msm: event"); return ZKG_ERROR; }
     }
-    J.resume = false; J.defer_reduce = false; J.window_hint = saved_hint;
-    if (rc != ZKG_OK) { (void)hipStreamSynchronize(J.copy); (void)hipStreamSynchronize(s); return ZKG_ERROR; }
+    const int c = (int)pick_geom(n, J.window_hint).c;                         // every piece under the whole job's window size
+    const int saved_hint = J.window_hint, saved_hint_k = K.window_hint;
+    hipEvent_t ev_j = J.ev_accum_wait, ev_k = K.ev_accum_wait;                // (kept here: the jobs' fields say "wait" only while a piece needs it)
+    J.ev_accum_wait = nullptr; K.ev_accum_wait = nullptr;
+    J.window_hint = c; K.window_hint = c; K.bucket_owner = &J; K.w0 = 0; K.ws = 1; K.one_pass_sort = false;
+    if (two_jobs) { ZK_HIP(hipEventRecord(ev_k, s)); ZK_HIP(hipStreamWaitEvent(K.stream, ev_k, 0)); }      // the side stream starts behind whatever the caller queued
+    int rc = ZKG_OK; bool started = false; MsmJob *prev = nullptr;
+    for (int k = 0; k < P && rc == ZKG_OK; ++k) {
+        if (cut[k + 1] == cut[k] && k + 1 < P) continue;                      // (an empty piece; the last one always runs: it carries the reduction)
+        MsmJob &W = (two_jobs && ((P - 1 - k) & 1)) ? K : J;
+        MsmBases piece = set; piece.p = reinterpret_cast<const char *>(d_bases) + cut[k] * sizeof(G1Affine);
+        W.resume = started; W.defer_reduce = k + 1 < P; started = true;
+        // this piece's accumulation waits for the previous piece's (other job, same buckets): an event recorded behind that job's launches
+        W.ev_accum_wait = nullptr;
+        if (prev && prev != &W) {
+            hipEvent_t e = prev == &J ? ev_j : ev_k;
+            if (hipEventRecord(e, prev->stream) != hipSuccess) { rc = ZKG_ERROR; break; }
+            W.ev_accum_wait = e;
+        }
+        if (hipStreamWaitEvent(W.stream, J.ev_piece[k], 0) != hipSuccess) { rc = ZKG_ERROR; break; }
+        rc = msm_job_launch(&W, &piece, 1, d_sc + 8 * cut[k], cut[k + 1] - cut[k], mont, nullptr);
+        prev = &W;
+    }
+    J.resume = false; J.defer_reduce = false; J.window_hint = saved_hint; J.ev_accum_wait = ev_j;
+    K.resume = false; K.defer_reduce = false; K.window_hint = saved_hint_k; K.ev_accum_wait = ev_k; K.bucket_owner = nullptr;
+    if (rc != ZKG_OK) { (void)hipStreamSynchronize(J.copy); if (K.stream) (void)hipStreamSynchronize(K.stream); (void)hipStreamSynchronize(s); return ZKG_ERROR; }
     return msm_job_finish(&J, out, nullptr);
 }
 
@@ -1644,6 +1679,18 @@ void msm_release_all() {
     for (auto &gr : j.group) gr.release();
     if (j.aux) { (void)hipStreamSynchronize(j.aux); (void)hipStreamDestroy(j.aux); j.aux = nullptr; }      // (a later zkg_init may pick another device)
     j.hs_scalars.release();
+    {
+        MsmJob &k = g_piece_job;
+        if (k.stream) (void)hipStreamSynchronize(k.stream);
+        for (DevBuf *b : {&k.digits, &k.hist, &k.counts, &k.offsets, &k.scan_sums, &k.class_hist, &k.order, &k.sorted, &k.rx_tmp, &k.rx_meta}) b->release();
+        for (auto &gr : k.group) gr.release();
+        if (k.aux) { (void)hipStreamSynchronize(k.aux); (void)hipStreamDestroy(k.aux); k.aux = nullptr; }
+        if (k.ev_fork) { (void)hipEventDestroy(k.ev_fork); k.ev_fork = nullptr; }
+        if (k.ev_join) { (void)hipEventDestroy(k.ev_join); k.ev_join = nullptr; }
+        if (k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; k.own_stream = false; }
+        if (k.ev_accum_wait) { (void)hipEventDestroy(k.ev_accum_wait); k.ev_accum_wait = nullptr; }
+        if (j.ev_accum_wait) { (void)hipEventDestroy(j.ev_accum_wait); j.ev_accum_wait = nullptr; }
+    }
     if (j.copy) { (void)hipStreamSynchronize(j.copy); (void)hipStreamDestroy(j.copy); j.copy = nullptr; }
     for (auto &e : j.ev_piece) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (j.ev_fork) { (void)hipEventDestroy(j.ev_fork); j.ev_fork = nullptr; }
