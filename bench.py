@@ -325,6 +325,28 @@ def prove_leg(zkg, torch, args, with_cpu, logm):
         g["speedup_vs_cpu_1core"] = round(cpu_dt / dt, 1)
         g["speedup_note"] = "against the single-thread PORT (oracle restatement), not libsnark's own x86-64 assembly build; a ratio says nothing about kernel quality"
     crs.free(); kp.free(); ck.free()
+    # the SAME credential on the REFERENCE's relation: zklaim_gadget.cpp:583-699 assigns the pack_PL / pack_REF / pack_OPS packings but never
+    # generates their constraints, so its R1CS is 78 rows per payload smaller than the hardened shape proved above
+    # (ZKG_CIRCUIT_REFERENCE_QUIRK rebuilds it).  Same payloads, own key, 30 proofs: the "zklaim gadget" half of the metric named on the
+    # reference's shape as well.
+    try:
+        ckq = zkg.ZklaimCircuit(ctx, reference_quirk=True)
+        wq = ckq.witness()
+        kpq = zkg.Keypair(ckq.r1cs, splitmix_fr(5, SEED + 4))
+        crsq = zkg.Crs(kpq.pk)
+        for _ in range(4):
+            rcq, proofq = crsq.prove(wq, rs[0], rs[1])
+        eachq = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); crsq.prove(wq, rs[0], rs[1]); eachq.append(time.perf_counter() - t0)
+        dtq = sum(eachq) / reps
+        g["reference_shape_circuit"] = {"what": "ZKG_CIRCUIT_REFERENCE_QUIRK: the packings left unconstrained as zklaim_gadget.cpp:583-699 leaves them",
+                                        "num_constraints": int(ckq.r1cs.num_constraints), "num_variables": int(ckq.r1cs.num_variables), "domain_size": int(kpq.pk.domain_size or (1 << kpq.pk.log_m)),
+                                        "ms_per_proof": round(dtq * 1e3, 3), "proofs_per_sec": round(1.0 / dtq, 3), "ms_per_proof_stats": stats_ms(eachq),
+                                        "proof_verifies": bool(rcq == 0 and zkg.groth16_verify(kpq.vk_blob(), wq[:ckq.r1cs.num_inputs], proofq) == 0)}
+        crsq.free(); kpq.free(); ckq.free()
+    except Exception as exc:                                     # never lose the line over this extra
+        g["reference_shape_circuit"] = {"error": repr(exc)}
     return g
 
 

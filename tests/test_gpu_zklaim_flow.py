@@ -138,6 +138,22 @@ def test_c_caller_of_the_multi_gpu_entry_points(zkg, tmp_path):
     assert out.returncode == 0 and "ok" in out.stdout
 
 
+def test_c_caller_shards_one_proof(zkg, tmp_path):
+    """tests/c/sharded_proof_demo.c: ONE credential proved from plain C with its H query sharded over devices (zkg_crs_shard_h) — the
+    134 bytes equal the unsharded proof's and verify; 3 shards on three GPUs when the box has them, on device 0 otherwise"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sharded_proof_demo")
+    so_dir = os.path.join(root, "zklaim_amd")
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "sharded_proof_demo.c"), "-o", exe,
+                           os.path.join(so_dir, "libzkg.so"), "-lcrypto", "-Wl,-rpath," + so_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    for shards, payloads in ((3, 2), (2, 1)):
+        out = subprocess.run([exe, str(shards), str(payloads)], capture_output=True, text=True, timeout=300)
+        print(out.stdout, out.stderr[-500:])
+        assert out.returncode == 0 and "identical" in out.stdout and "verification ok" in out.stdout
+
+
 def test_seam_is_reentrant(zkg):
     """The reference seam is single-caller (it closes fd 1, mutates libff globals and re-runs init_public_params per call,
     libsnark_wrapper.cpp:197-212); this one takes callers from several threads: two credentials with their own keys, each proved and

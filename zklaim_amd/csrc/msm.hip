@@ -979,7 +979,10 @@ struct MsmJob {
     // `defer_reduce` — more pieces follow: no reduction, nothing copied back; `c_fixed` — every piece uses the whole job's window size
     bool resume = false, defer_reduce = false; bool last_out29 = false;
     // a second job that alternates with this one over the pieces of one multi-exponentiation accumulates into THIS job's buckets
-    MsmJob *bucket_owner = nullptr; hipEvent_t ev_accum_wait = nullptr;    // ev_accum_wait: the other job's accumulation (same buckets) that must be through first
+    MsmJob *bucket_owner = nullptr;
+    // the digit sort may run on a stream of its own (high priority: its small kernels get the compute units an accumulation frees first);
+    // ev_sorted orders the accumulation behind it, ev_acc_done the next sort of this job's buffers behind the accumulation that reads them
+    hipStream_t sort_stream = nullptr; hipEvent_t ev_sorted = nullptr, ev_acc_done = nullptr;
     uint32_t w0 = 0, ws = 1;           // window subset of the next launches (window-sharded multi-GPU runs)
     bool empty = false;
     // bases resident, scalars in host memory (msm_g1_host_scalars): device copy of the scalars, the copy stream and one event per piece
@@ -1029,12 +1032,15 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if constexpr (sizeof(F) == sizeof(Fq)) {
         if (ns == 1 && !accum32 && plain) {
             use29 = true;
-            if (job->converted_aside) ZK_HIP(hipStreamWaitEvent(s, job->ev_join, 0));       // converted beside the sort (msm_job_launch)
+            if (sets[0].p29) rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29);       // the caller made the records (a piece of a piece-wise job)
             else {
-                if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
-                hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+                if (job->converted_aside) ZK_HIP(hipStreamWaitEvent(s, job->ev_join, 0));   // converted beside the sort (msm_job_launch)
+                else {
+                    if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+                    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+                }
+                rec29 = gr.bases29.as<Affine29>();
             }
-            rec29 = gr.bases29.as<Affine29>();
         } else if (ns == 1 && !accum32 && !d_gather && sets[0].p29 && !sets[0].remap && sets[0].index_sub == 0) {
             use29 = true; rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
         }
@@ -1046,7 +1052,6 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     MsmJob *owner = job->bucket_owner ? job->bucket_owner : job;                // (whose buckets these are)
     if (resume && !(out29 && owner->last_out29)) { set_error("msm: a piece can only continue 29-bit buckets"); return ZKG_ERROR; }
     owner->last_out29 = out29;
-    if (job->ev_accum_wait) ZK_HIP(hipStreamWaitEvent(s, job->ev_accum_wait, 0));      // the sort above ran beside it; the buckets are shared
     if (time_it) g_dominant_timer.begin(s);
     bool done_ba = false;
     if constexpr (sizeof(F) == sizeof(Fq)) {
@@ -1217,7 +1222,7 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
     const MsmGeom g0 = job->g; const size_t n0 = job->n;                        // as the scalars see them (k_digits)
     if (job->merge > 1) { job->g.W /= job->merge; job->g.Wt = job->g.W; job->n *= job->merge; }     // rows of the digit array read `merge` at a time from here on
     const MsmGeom g = job->g; const size_t n = job->n;
-    hipStream_t s = job->stream;
+    hipStream_t s = job->sort_stream ? job->sort_stream : job->stream;
     const size_t total = (size_t)g.W * g.B;
     uint32_t slice_len = (uint32_t)std::min<size_t>(65536, std::max<size_t>(4096, ((n + 15) / 16 + 1023) / 1024 * 1024));
     uint32_t S = (uint32_t)std::max<size_t>(1, (n + slice_len - 1) / slice_len);
@@ -1303,7 +1308,8 @@ void msm_job_destroy(MsmJob *j) {
 }
 
 static MsmJob g_default_job;          // the synchronous entry points share one job (serialised by its mutex); only it feeds the kernel timer
-static MsmJob g_piece_job;            // msm_g1_host_scalars: odd pieces sort here, on a stream of their own, beside the even pieces' accumulation (under g_default_job's mutex)
+static MsmJob g_piece_job;            // msm_g1_host_scalars: the second set of sort buffers its pieces alternate over (used under g_default_job's mutex)
+static hipStream_t g_sort_hi = nullptr;   // and the high-priority stream their digit sorts run on
 
 // enqueue: one digit sort of the scalars (element d_gather[i] of d_scalars when a gather list is given), then one accumulate + reduce
 // per base set
@@ -1334,7 +1340,7 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
     {
         static const bool accum32 = getenv("ZKG_ACCUM_32") != nullptr, inline29 = getenv("ZKG_TO29_INLINE") != nullptr;       // A/B switches
         MsmGroup &g1 = job->group[0];
-        if (!accum32 && !inline29 && !any_table && !d_gather && g1.nsets == 1 && by_field[0][0].index_sub == 0 && !by_field[0][0].remap) {
+        if (!accum32 && !inline29 && !any_table && !d_gather && g1.nsets == 1 && by_field[0][0].index_sub == 0 && !by_field[0][0].remap && !by_field[0][0].p29) {
             if (!job->aux && (hipStreamCreateWithFlags(&job->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&job->ev_fork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&job->ev_join, hipEventDisableTiming) != hipSuccess)) { set_error("msm: side stream"); return ZKG_ERROR; }
             if (g1.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
@@ -1348,6 +1354,9 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
     // an error return after the fork must not leave the side stream reading the caller's bases (a synchronous caller may free them next)
     auto fail = [&] { if (job->converted_aside) { (void)hipStreamSynchronize(job->aux); job->converted_aside = false; } return ZKG_ERROR; };
     if (sort_digits(job, d_scalars, scalars_mont, d_gather)) return fail();
+    if (job->sort_stream && job->sort_stream != job->stream) {                 // the accumulation (job->stream) behind the sort
+        if (hipEventRecord(job->ev_sorted, job->sort_stream) != hipSuccess || hipStreamWaitEvent(job->stream, job->ev_sorted, 0) != hipSuccess) return fail();
+    }
     if (job->merge > 1) {
         for (int k = 0; k < 2; ++k) for (int i = 0; i < job->group[k].nsets; ++i) by_field[k][i].level_stride *= job->merge;
     }
@@ -1446,42 +1455,53 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
         ZK_HIP(hipMemcpyAsync(d_sc + 8 * cut[k], h_scalars + 8 * cut[k], (cut[k + 1] - cut[k]) * 32, hipMemcpyHostToDevice, J.copy));
         ZK_HIP(hipEventRecord(J.ev_piece[k], J.copy));
     }
-    // Pieces alternate between two jobs (two streams, two sets of sort buffers, ONE set of buckets): the digit sort of piece k + 1 runs
-    // beside the accumulation of piece k — its small dependent launches and single-workgroup scans cost the chip little there, and a
-    // third of a step when they stand alone.  The last piece is the caller's job and stream (it carries the reduction and the result).
+    // Pieces alternate between two jobs — two sets of sort buffers, ONE set of buckets, all accumulations in order on the caller's stream —
+    // and every piece's digit sort runs on a high-priority stream of its own beside the accumulation of the piece before it: the sort's
+    // small dependent launches and single-workgroup scans stand a third of a step when alone and cost the accumulation little beside it
+    // (without the priority they crawl: k_rx_count 134 us instead of 11).  The bases' 29-bit records are made once for all pieces, on
+    // the side stream, under the first upload.
     static const bool two_jobs = getenv("ZKG_MSM_PIECES_ONE_STREAM") == nullptr;                          // A/B switch
     MsmJob &K = g_piece_job;
-    if (two_jobs && !K.stream) {
-        if (hipStreamCreateWithFlags(&K.stream, hipStreamNonBlocking) != hipSuccess) { K.stream = nullptr; set_error("msm: piece stream"); return ZKG_ERROR; }
-        K.own_stream = true;
-        if (hipEventCreateWithFlags(&K.ev_accum_wait, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&J.ev_accum_wait, hipEventDisableTiming) != hipSuccess) { set_error("msm: event"); return ZKG_ERROR; }
+    if (two_jobs && !g_sort_hi) {
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        bool ok = hipStreamCreateWithPriority(&g_sort_hi, hipStreamNonBlocking, hi) == hipSuccess;
+        for (MsmJob *w : {&J, &K}) ok = ok && hipEventCreateWithFlags(&w->ev_sorted, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_acc_done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { g_sort_hi = nullptr; set_error("msm: sort stream"); return ZKG_ERROR; }
     }
+    hipStream_t s_hi = two_jobs ? g_sort_hi : nullptr;
+    // all bases as 29-bit records, once (k_bases_to29 on the job's side stream: it runs under the first piece's upload)
+    if (!J.aux && (hipStreamCreateWithFlags(&J.aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&J.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                   hipEventCreateWithFlags(&J.ev_join, hipEventDisableTiming) != hipSuccess)) { set_error("msm: side stream"); return ZKG_ERROR; }
+    if (J.group[0].bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+    ZK_HIP(hipEventRecord(J.ev_fork, s));                                     // behind whatever the caller queued (the work that made the bases), and the last call's accumulation
+    ZK_HIP(hipStreamWaitEvent(J.aux, J.ev_fork, 0));
+    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, J.aux, reinterpret_cast<const Affine<Fq> *>(d_bases), n, J.group[0].bases29.as<Affine29>());
+    ZK_HIP(hipEventRecord(J.ev_join, J.aux));
+    ZK_HIP(hipStreamWaitEvent(s, J.ev_join, 0));
+    if (s_hi) ZK_HIP(hipStreamWaitEvent(s_hi, J.ev_fork, 0));
     const int c = (int)pick_geom(n, J.window_hint).c;                         // every piece under the whole job's window size
     const int saved_hint = J.window_hint, saved_hint_k = K.window_hint;
-    hipEvent_t ev_j = J.ev_accum_wait, ev_k = K.ev_accum_wait;                // (kept here: the jobs' fields say "wait" only while a piece needs it)
-    J.ev_accum_wait = nullptr; K.ev_accum_wait = nullptr;
-    J.window_hint = c; K.window_hint = c; K.bucket_owner = &J; K.w0 = 0; K.ws = 1; K.one_pass_sort = false;
-    if (two_jobs) { ZK_HIP(hipEventRecord(ev_k, s)); ZK_HIP(hipStreamWaitEvent(K.stream, ev_k, 0)); }      // the side stream starts behind whatever the caller queued
-    int rc = ZKG_OK; bool started = false; MsmJob *prev = nullptr;
+    J.window_hint = c; K.window_hint = c; K.bucket_owner = &J; K.w0 = 0; K.ws = 1; K.one_pass_sort = false; K.stream = s;
+    int rc = ZKG_OK; bool started = false; bool used[2] = {false, false};
     for (int k = 0; k < P && rc == ZKG_OK; ++k) {
         if (cut[k + 1] == cut[k] && k + 1 < P) continue;                      // (an empty piece; the last one always runs: it carries the reduction)
-        MsmJob &W = (two_jobs && ((P - 1 - k) & 1)) ? K : J;
+        const int which = (two_jobs && ((P - 1 - k) & 1)) ? 1 : 0;            // the last piece is the default job's: it carries the reduction and the result
+        MsmJob &W = which ? K : J;
         MsmBases piece = set; piece.p = reinterpret_cast<const char *>(d_bases) + cut[k] * sizeof(G1Affine);
+        piece.p29 = J.group[0].bases29.as<Affine29>() + cut[k];
         W.resume = started; W.defer_reduce = k + 1 < P; started = true;
-        // this piece's accumulation waits for the previous piece's (other job, same buckets): an event recorded behind that job's launches
-        W.ev_accum_wait = nullptr;
-        if (prev && prev != &W) {
-            hipEvent_t e = prev == &J ? ev_j : ev_k;
-            if (hipEventRecord(e, prev->stream) != hipSuccess) { rc = ZKG_ERROR; break; }
-            W.ev_accum_wait = e;
-        }
-        if (hipStreamWaitEvent(W.stream, J.ev_piece[k], 0) != hipSuccess) { rc = ZKG_ERROR; break; }
+        W.sort_stream = s_hi;
+        hipStream_t ss = s_hi ? s_hi : s;
+        // this piece's sort: after its scalars have landed, and after the accumulation that last read this job's sort buffers
+        if (hipStreamWaitEvent(ss, J.ev_piece[k], 0) != hipSuccess) { rc = ZKG_ERROR; break; }
+        if (s_hi && used[which] && hipStreamWaitEvent(s_hi, W.ev_acc_done, 0) != hipSuccess) { rc = ZKG_ERROR; break; }
         rc = msm_job_launch(&W, &piece, 1, d_sc + 8 * cut[k], cut[k + 1] - cut[k], mont, nullptr);
-        prev = &W;
+        if (rc == ZKG_OK && s_hi && hipEventRecord(W.ev_acc_done, s) != hipSuccess) rc = ZKG_ERROR;
+        used[which] = true;
     }
-    J.resume = false; J.defer_reduce = false; J.window_hint = saved_hint; J.ev_accum_wait = ev_j;
-    K.resume = false; K.defer_reduce = false; K.window_hint = saved_hint_k; K.ev_accum_wait = ev_k; K.bucket_owner = nullptr;
-    if (rc != ZKG_OK) { (void)hipStreamSynchronize(J.copy); if (K.stream) (void)hipStreamSynchronize(K.stream); (void)hipStreamSynchronize(s); return ZKG_ERROR; }
+    J.resume = false; J.defer_reduce = false; J.window_hint = saved_hint; J.sort_stream = nullptr;      // (the other entry points sort on the job's own stream)
+    K.resume = false; K.defer_reduce = false; K.window_hint = saved_hint_k; K.bucket_owner = nullptr; K.sort_stream = nullptr; K.stream = nullptr;
+    if (rc != ZKG_OK) { (void)hipStreamSynchronize(J.copy); if (s_hi) (void)hipStreamSynchronize(s_hi); (void)hipStreamSynchronize(s); return ZKG_ERROR; }
     return msm_job_finish(&J, out, nullptr);
 }
 
@@ -1681,15 +1701,17 @@ void msm_release_all() {
     j.hs_scalars.release();
     {
         MsmJob &k = g_piece_job;
-        if (k.stream) (void)hipStreamSynchronize(k.stream);
+        if (g_sort_hi) { (void)hipStreamSynchronize(g_sort_hi); (void)hipStreamDestroy(g_sort_hi); g_sort_hi = nullptr; }
         for (DevBuf *b : {&k.digits, &k.hist, &k.counts, &k.offsets, &k.scan_sums, &k.class_hist, &k.order, &k.sorted, &k.rx_tmp, &k.rx_meta}) b->release();
         for (auto &gr : k.group) gr.release();
         if (k.aux) { (void)hipStreamSynchronize(k.aux); (void)hipStreamDestroy(k.aux); k.aux = nullptr; }
         if (k.ev_fork) { (void)hipEventDestroy(k.ev_fork); k.ev_fork = nullptr; }
         if (k.ev_join) { (void)hipEventDestroy(k.ev_join); k.ev_join = nullptr; }
-        if (k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; k.own_stream = false; }
-        if (k.ev_accum_wait) { (void)hipEventDestroy(k.ev_accum_wait); k.ev_accum_wait = nullptr; }
-        if (j.ev_accum_wait) { (void)hipEventDestroy(j.ev_accum_wait); j.ev_accum_wait = nullptr; }
+        for (MsmJob *w : {&j, &k}) {
+            if (w->ev_sorted) { (void)hipEventDestroy(w->ev_sorted); w->ev_sorted = nullptr; }
+            if (w->ev_acc_done) { (void)hipEventDestroy(w->ev_acc_done); w->ev_acc_done = nullptr; }
+        }
+        k.stream = nullptr;
     }
     if (j.copy) { (void)hipStreamSynchronize(j.copy); (void)hipStreamDestroy(j.copy); j.copy = nullptr; }
     for (auto &e : j.ev_piece) if (e) { (void)hipEventDestroy(e); e = nullptr; }
