@@ -566,7 +566,21 @@ def main():
         # BASELINE configs[4]: 2^23 points per GPU (2^26 at 8 GPUs), same exchange; every rank takes part, rank 0 reports
         # (msm_leg agrees on every rank's setup before its first collective and returns None on all ranks if one of them failed)
         c5 = msm_leg(zkg, torch, dist, 23, 0x100 * rank, 3, use_dist, world)
+        # the north star's scaling claim is a STRONG-scaling one (the 2^26-point job on 8 GPUs against the same job on one): rank 0 runs the
+        # whole job's points (world x 2^23) alone while the others wait, and the ratio is reported beside the leg
+        ref = None
         if rank == 0 and c5:
+            try:
+                ref = msm_leg(zkg, torch, None, 23 + max(0, (world - 1).bit_length()), 0x900, 3, False, 1) if world > 1 else {"ms_per_step": c5["ms_per_step"], "total_points": c5["total_points"]}
+            except Exception as exc:
+                print("config-5 single-GPU reference failed:", exc, file=sys.stderr)
+        if use_dist:
+            dist.barrier()
+        if rank == 0 and c5:
+            if ref and ref.get("total_points") == c5["total_points"]:
+                c5["strong_scaling"] = {"single_gpu_ms_for_the_same_total_points": ref["ms_per_step"], "n_gpus": world,
+                                        "speedup_vs_one_gpu": round(ref["ms_per_step"] / c5["ms_per_step"], 3),
+                                        "note": "the whole job's points on ONE GPU (rank 0, the others idle) against the same points sharded over all ranks, exchange and EC sum included"}
             line["msm_config5"] = c5
     if rank == 0:
         sys.stdout.flush()
@@ -574,6 +588,14 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     zkg.shutdown()
+    # a run whose ranks disagree on the combined point (or whose upload-inclusive step differs from the resident one) is not a measurement
+    bad = not same_everywhere or (resident is not None and not (resident["same_result"] and resident["one_upload_then_resident_call"]["same_result"]))
+    c5_line = line.get("msm_config5") if rank == 0 else None
+    if c5_line and not (c5_line.get("all_ranks_same_result") and c5_line.get("partial_equals_sum_of_2p20_pieces")):
+        bad = True
+    if bad:
+        print("bench: results differ (all_ranks_same_result / same_result false): the line above is NOT a valid measurement", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

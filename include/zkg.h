@@ -180,6 +180,11 @@ zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const 
 void zkg_msm_g1_shards_free(zkg_msm_shards *shards);
 size_t zkg_msm_g1_shards_count(const zkg_msm_shards *shards, size_t *points);
 int zkg_msm_g1_multi(const zkg_msm_shards *shards, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac);
+/* With ZKG_MULTI_RCCL=1 in the environment zkg_msm_g1_multi exchanges the shards' partial points with an RCCL all-gather (one
+ * communicator per shard from ncclCommInitAll, one group call per multi-exponentiation, 96 bytes per GPU over xGMI) before the sum; the
+ * library is opened at run time.  Needs every shard on its own device (RCCL refuses a device listed twice: such a handle keeps the host
+ * exchange).  zkg_multi_rccl_calls: how many calls of this process went through the collective.                                      */
+unsigned zkg_multi_rccl_calls(void);
 
 /* ---- fixed-base batch: out[i] = scalars[i] * base (affine out).  The batch_exp of
  *      libsnark's generator (snark.cpp:91); used here to build synthetic bases on device. */

@@ -341,3 +341,27 @@ def test_host_scalars_pieces_equal_the_resident_msm(zkg, oracle, n):
     exp2 = zkg.msm_g1_dev(d_bases2.data_ptr(), d_sc2.data_ptr(), n)
     assert np.array_equal(zkg.msm_g1_host_scalars(d_bases2.data_ptr(), h_sc2.data_ptr(), n), exp2)
     assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_sc.data_ptr(), n), exp)       # and the job is clean afterwards
+
+
+def test_multi_device_exchange_over_rccl(zkg, oracle):
+    """ZKG_MULTI_RCCL=1: zkg_msm_g1_multi all-gathers the shards' 96-byte partials with RCCL (ncclCommInitAll in ONE process, the library
+    opened at run time) before the sum — the collective form of the exchange BASELINE.json's north star names.  One shard per DISTINCT
+    device: as many as the box has (one here), same point as the oracle, and the call counter moves; a handle that lists a device twice
+    keeps the host exchange (RCCL refuses duplicate devices) and still returns the same point."""
+    import torch
+    n = 3000
+    _, bases, _ = dev_bases_g1(zkg, n, 0x7CC1)
+    sc = random_fr_canonical(n, 0x7CC2)
+    exp = oracle.msm_g1(bases, sc)
+    ndev = min(torch.cuda.device_count(), 8)
+    before = zkg.lib().zkg_multi_rccl_calls()
+    sh = zkg.MsmShards(bases, list(range(ndev)))
+    got = _with_env("ZKG_MULTI_RCCL", 1, lambda: sh.msm(sc))
+    got2 = _with_env("ZKG_MULTI_RCCL", 1, lambda: sh.msm(sc))
+    sh.free()
+    assert np.array_equal(got, exp) and np.array_equal(got2, exp)
+    assert zkg.lib().zkg_multi_rccl_calls() == before + 2, "the exchange did not go through RCCL"
+    dup = zkg.MsmShards(bases, [0, 0])
+    got3 = _with_env("ZKG_MULTI_RCCL", 1, lambda: dup.msm(sc))
+    dup.free()
+    assert np.array_equal(got3, exp) and zkg.lib().zkg_multi_rccl_calls() == before + 2

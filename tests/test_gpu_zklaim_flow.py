@@ -136,6 +136,13 @@ def test_c_caller_of_the_multi_gpu_entry_points(zkg, tmp_path):
     out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr[-500:])
     assert out.returncode == 0 and "ok" in out.stdout
+    # the same program with the RCCL exchange switched on: a plain C process (no PyTorch in it) opens the system's librccl at run time;
+    # one shard per distinct device (one on this box)
+    import torch
+    env = dict(os.environ, ZKG_MULTI_RCCL="1")
+    out = subprocess.run([exe, str(max(1, min(torch.cuda.device_count(), 8)))], capture_output=True, text=True, timeout=300, env=env)
+    print(out.stdout, out.stderr[-500:])
+    assert out.returncode == 0 and "ok" in out.stdout
 
 
 def test_c_caller_shards_one_proof(zkg, tmp_path):

@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
     "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h", "zkg_msm_g1_bases_upload", "zkg_msm_g1_resident", "zkg_msm_g1_bases_free",
-    "zkg_prover_peak_in_flight", "zkg_msm_g1_host_scalars",
+    "zkg_prover_peak_in_flight", "zkg_msm_g1_host_scalars", "zkg_multi_rccl_calls",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]

@@ -12,6 +12,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>                  // types and prototypes only: the library is opened at run time (rccl_api), never linked
 
 namespace zk {
 
@@ -465,11 +467,68 @@ int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t
 //      bytes each — are added on the host.  There is no data-path collective: RCCL has no elliptic-curve reduction, and a sum of
 //      ndev points is not worth a kernel.  (The one-process-per-GPU form of the same exchange is zklaim_amd/dist.py over RCCL.)
 namespace { struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); } }; }   // also on an exception
+// RCCL for the exchange of the shards' partial points (ZKG_MULTI_RCCL=1; BASELINE.json north_star: "RCCL ... of partial ... sums over xGMI").
+// One process drives every GPU, so the communicators come from ncclCommInitAll and the all-gather of the 96-byte partials is one group call.
+// The library is dlopen'ed on first use (a process that already holds PyTorch's copy gets that one): libzkg.so itself links no RCCL, and the
+// single-GPU entry points never touch it.
+extern "C++" {
+namespace {
+struct RcclApi {
+    void *lib = nullptr; bool tried = false;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+};
+RcclApi &rccl_api() {
+    static RcclApi a; static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!a.tried) {
+        a.tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) { a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
+        if (a.lib) {
+            a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.lib, "ncclCommInitAll"); a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+            a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather"); a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd"); a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        }
+    }
+    return a;
+}
+}  // namespace
+}  // extern "C++"
 struct zkg_msm_shards {
-    struct Shard { int device = 0; size_t first = 0, n = 0; DevBuf bases, scalars; MsmJob *job = nullptr; };
+    struct Shard { int device = 0; size_t first = 0, n = 0; DevBuf bases, scalars; MsmJob *job = nullptr; DevBuf xsend, xrecv; ncclComm_t comm = nullptr; };
     std::vector<Shard> shards; size_t n = 0;
     std::mutex mu;                       // a call owns every shard's scalar buffer, job workspace and stream: callers of one handle take turns
+    int rccl_state = 0;                  // 0 not tried, 1 communicators up, -1 unavailable (no library, a device listed twice, init failed): host exchange
+    uint64_t *pinned = nullptr;          // ndev x 12 words: the partials on their way to the devices, and the gathered set coming back
 };
+// the shards' communicators, on first use: one rank per shard, which RCCL only allows on distinct devices
+static bool shards_rccl_ready(zkg_msm_shards *h) {
+    if (h->rccl_state) return h->rccl_state > 0;
+    h->rccl_state = -1;
+    const size_t ns = h->shards.size();
+    for (size_t i = 0; i < ns; ++i) for (size_t j = i + 1; j < ns; ++j) if (h->shards[i].device == h->shards[j].device) return false;   // (the single-GPU rehearsal lists a device twice)
+    RcclApi &R = rccl_api();
+    if (!R.ok()) return false;
+    std::vector<int> devs(ns); std::vector<ncclComm_t> comms(ns, nullptr);
+    for (size_t i = 0; i < ns; ++i) devs[i] = h->shards[i].device;
+    int cur = 0; (void)hipGetDevice(&cur);
+    bool ok = R.CommInitAll(comms.data(), (int)ns, devs.data()) == ncclSuccess;
+    for (size_t i = 0; ok && i < ns; ++i) {
+        zkg_msm_shards::Shard &sh = h->shards[i];
+        sh.comm = comms[i];
+        ok = hipSetDevice(sh.device) == hipSuccess && !sh.xsend.reserve(96) && !sh.xrecv.reserve(ns * 96);
+    }
+    ok = ok && hipHostMalloc((void **)&h->pinned, 2 * ns * 96, hipHostMallocDefault) == hipSuccess;
+    (void)hipSetDevice(cur);
+    if (!ok) { for (size_t i = 0; i < ns; ++i) if (comms[i]) { (void)R.CommDestroy(comms[i]); h->shards[i].comm = nullptr; } return false; }
+    h->rccl_state = 1;
+    return true;
+}
 
 int zkg_init_multi(const int *devices, int ndev) {
     if (!devices || ndev < 1) { set_error("zkg_init_multi: bad argument"); return ZKG_ERROR; }
@@ -519,12 +578,18 @@ zkg_msm_shards *zkg_msm_g1_shards_upload(const uint64_t *bases, size_t n, const 
 void zkg_msm_g1_shards_free(zkg_msm_shards *h) {
     if (!h) return;
     int cur = 0; (void)hipGetDevice(&cur);
-    for (auto &sh : h->shards) { (void)hipSetDevice(sh.device); msm_job_destroy(sh.job); sh.bases.release(); sh.scalars.release(); }
+    for (auto &sh : h->shards) {
+        (void)hipSetDevice(sh.device); msm_job_destroy(sh.job); sh.bases.release(); sh.scalars.release(); sh.xsend.release(); sh.xrecv.release();
+        if (sh.comm) (void)rccl_api().CommDestroy(sh.comm);
+    }
+    if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipSetDevice(cur);
     delete h;
 }
 size_t zkg_msm_g1_shards_count(const zkg_msm_shards *h, size_t *points) { if (points) *points = h ? h->n : 0; return h ? h->shards.size() : 0; }
 
+static std::atomic<unsigned> g_multi_rccl_calls{0};                                // zkg_msm_g1_multi calls that exchanged over RCCL (zkg_multi_rccl_calls)
+unsigned zkg_multi_rccl_calls(void) { return g_multi_rccl_calls.load(); }
 static int zkg_msm_g1_multi_impl(const zkg_msm_shards *h_, const uint64_t *scalars, uint64_t out_jac[12], uint64_t *partials_jac) {
     zkg_msm_shards *h = const_cast<zkg_msm_shards *>(h_);
     if (!h || !out_jac || (h->n && !scalars)) { set_error("zkg_msm_g1_multi: bad argument"); return ZKG_ERROR; }
@@ -548,6 +613,37 @@ static int zkg_msm_g1_multi_impl(const zkg_msm_shards *h_, const uint64_t *scala
         (void)hipSetDevice(cur);
     }
     for (int r : rc) if (r) return ZKG_ERROR;
+    // the exchange.  Default: the partials are already on the host (each shard's finish step lands its chunk sums there), so they are simply
+    // added.  ZKG_MULTI_RCCL=1: every device all-gathers the normalised partials over RCCL (xGMI) first and the sum is taken over what device 0
+    // received — the collective form of the same 96-byte-per-GPU exchange (one more round trip; the points must agree with the host's copies).
+    const bool want_rccl = getenv("ZKG_MULTI_RCCL") != nullptr;                  // (read per call: the tests switch it inside one process)
+    if (want_rccl && shards_rccl_ready(h)) {
+        RcclApi &R = rccl_api();
+        int cur = 0; (void)hipGetDevice(&cur);
+        bool ok = true;
+        for (size_t i = 0; i < ns && ok; ++i) {
+            store_norm(h->pinned + 12 * i, part[i]);
+            ok = hipSetDevice(h->shards[i].device) == hipSuccess &&
+                 hipMemcpyAsync(h->shards[i].xsend.p, h->pinned + 12 * i, 96, hipMemcpyHostToDevice, msm_job_stream(h->shards[i].job)) == hipSuccess;
+        }
+        ok = ok && R.GroupStart() == ncclSuccess;
+        for (size_t i = 0; i < ns && ok; ++i)
+            ok = hipSetDevice(h->shards[i].device) == hipSuccess &&
+                 R.AllGather(h->shards[i].xsend.p, h->shards[i].xrecv.p, 12, ncclUint64, h->shards[i].comm, msm_job_stream(h->shards[i].job)) == ncclSuccess;
+        ok = R.GroupEnd() == ncclSuccess && ok;
+        uint64_t *got = h->pinned + 12 * ns;
+        ok = ok && hipSetDevice(h->shards[0].device) == hipSuccess &&
+             hipMemcpyAsync(got, h->shards[0].xrecv.p, ns * 96, hipMemcpyDeviceToHost, msm_job_stream(h->shards[0].job)) == hipSuccess;
+        for (size_t i = 0; i < ns && ok; ++i) ok = hipSetDevice(h->shards[i].device) == hipSuccess && hipStreamSynchronize(msm_job_stream(h->shards[i].job)) == hipSuccess;
+        (void)hipSetDevice(cur);
+        if (!ok) { set_error("zkg_msm_g1_multi: the RCCL exchange failed"); return ZKG_ERROR; }
+        if (memcmp(got, h->pinned, ns * 96) != 0) { set_error("zkg_msm_g1_multi: the gathered partials differ from the shards' own"); return ZKG_ERROR; }
+        G1 acc = G1::inf();
+        for (size_t i = 0; i < ns; ++i) { if (partials_jac) memcpy(partials_jac + 12 * i, got + 12 * i, 96); acc.add(load_norm_g1(got + 12 * i)); }
+        store_norm(out_jac, acc);
+        g_multi_rccl_calls.fetch_add(1);
+        return ZKG_OK;
+    }
     G1 acc = G1::inf();
     for (size_t i = 0; i < ns; ++i) { if (partials_jac) store_norm(partials_jac + 12 * i, part[i]); acc.add(part[i]); }
     store_norm(out_jac, acc);
