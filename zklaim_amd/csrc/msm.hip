@@ -1489,6 +1489,11 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
     cut[P] = n;
     for (int k = P - 1; k >= 1; --k) cut[k] = (cut[k + 1] / 2) & ~(size_t)255;
     cut[0] = 0;
+    if (const char *e = getenv("ZKG_MSM_CUTS")) {                              // tuning aid: the piece boundaries in 64ths of n, e.g. "8,32" -> n/8, 3n/8, n/2
+        int k = 1; const char *q = e;
+        while (*q && k < 8) { const long v = strtol(q, const_cast<char **>(&q), 10); if (v <= 0 || v >= 64) break; cut[k++] = (n * (size_t)v / 64) & ~(size_t)255; if (*q == ',') ++q; }
+        if (k > 1) { P = k; cut[P] = n; for (int i = 1; i < P; ++i) if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1]; }
+    }
     for (int k = 0; k < P; ++k) {
         ZK_HIP(hipMemcpyAsync(d_sc + 8 * cut[k], h_scalars + 8 * cut[k], (cut[k + 1] - cut[k]) * 32, hipMemcpyHostToDevice, J.copy));
         ZK_HIP(hipEventRecord(J.ev_piece[k], J.copy));
