@@ -307,6 +307,8 @@ int zkg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t
 /* known-answer hook for the 29-bit group law of the bucket-reduction kernels (csrc/fq29.hip.hpp, xyzz29_add_quad): on the GPU,
  * out[i] = a[i] + b[i], then `chain` rounds of x <- 2x + b[i]; points as normalised Jacobian (12 limbs), host pointers.          */
 int zkg_g1_add_quad29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac);
+/* the same for the pair form the bucket reduction uses since round 4 (xyzz29_add_pair: lane 0 of a pair holds (X, ZZ), lane 1 (Y, ZZZ)) */
+int zkg_g1_add_pair29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac);
 
 /* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
  * average device ms per launch of the dominant kernel over the calls since the last reset */

@@ -98,3 +98,19 @@ def test_g1_quad_addition_29bit_vs_oracle(zkg, oracle):
             assert np.array_equal(got[i], exp), (chain, i)
     lane = zkg.g1_add_quad29(a, b, -1)                                       # the one-lane form of the same addition
     assert all(np.array_equal(lane[i], oracle.g1_sum(np.stack([a[i], b[i]]))) for i in range(n))
+    # the pair form (xyzz29_add_pair: two lanes per addition, the bucket reduction's since round 4): the same cases and chains, and long
+    # chains (33 and 129 dependent additions per pair) on the first points
+    for chain in (0, 1, 5):
+        got = zkg.g1_add_pair29(a, b, chain)
+        for i in range(n):
+            exp = oracle.g1_sum(np.stack([a[i], b[i]]))
+            for _ in range(chain):
+                exp = oracle.g1_sum(np.stack([exp, exp, b[i]]))
+            assert np.array_equal(got[i], exp), ("pair", chain, i)
+    for chain in (16, 64):
+        got = zkg.g1_add_pair29(a[:12], b[:12], chain)
+        for i in range(12):
+            exp = oracle.g1_sum(np.stack([a[i], b[i]]))
+            for _ in range(chain):
+                exp = oracle.g1_sum(np.stack([exp, exp, b[i]]))
+            assert np.array_equal(got[i], exp), ("pair", chain, i)

@@ -17,3 +17,8 @@ for waves in (256, 1024, 2048, 4096):
     a = np.tile(jac[:32], (n // 32 + 1, 1))[:n]; b = np.tile(jac[32:], (n // 32 + 1, 1))[:n]
     out = zkg.g1_add_quad29(a, b, 64)
     print(waves, "wavefronts", out[0][:2])
+for waves in (256, 1024, 2048, 4096):                       # the pair form: 32 pairs per wavefront
+    n = 32 * waves
+    a = np.tile(jac[:32], (n // 32 + 1, 1))[:n]; b = np.tile(jac[32:], (n // 32 + 1, 1))[:n]
+    out = zkg.g1_add_pair29(a, b, 64)
+    print(waves, "wavefronts (pairs)", out[0][:2])

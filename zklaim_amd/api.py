@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "zkg_keypair_pk", "zkg_keypair_swapped", "zkg_keypair_pk_blob", "zkg_keypair_vk_blob", "zkg_groth16_verify", "zkg_pairing_probe", "zkg_pairing_selfcheck",
     "zkg_compat_reset", "zkg_field_op", "zkg_init_multi", "zkg_msm_g1_shards_upload", "zkg_msm_g1_shards_free", "zkg_msm_g1_shards_count",
     "zkg_msm_g1_multi", "zkg_g1_add_quad29", "zkg_crs_shard_h", "zkg_msm_g1_bases_upload", "zkg_msm_g1_resident", "zkg_msm_g1_bases_free",
-    "zkg_prover_peak_in_flight", "zkg_msm_g1_host_scalars", "zkg_multi_rccl_calls",
+    "zkg_prover_peak_in_flight", "zkg_msm_g1_host_scalars", "zkg_multi_rccl_calls", "zkg_g1_add_pair29",
 ]
 # the reference's own seam, exported with its original names (zklaim.h:257-259)
 COMPAT_SYMBOLS = ["libsnark_trusted_setup", "libsnark_prove", "libsnark_verify"]
@@ -126,6 +126,13 @@ def g1_add_quad29(a_jac, b_jac, chain=0):
     """out[i] = a[i] + b[i] (then `chain` rounds of x <- 2x + b[i]) on the GPU through the 29-bit quad addition of the reduction kernels"""
     a = _u64(a_jac); b = _u64(b_jac); out = np.zeros_like(a)
     _check(lib().zkg_g1_add_quad29(_p(a), _p(b), C.c_size_t(a.size // 12), int(chain), _p(out)), "zkg_g1_add_quad29")
+    return out.reshape(-1, 12)
+
+
+def g1_add_pair29(a_jac, b_jac, chain=0):
+    """the same through the pair form of the addition (xyzz29_add_pair, the bucket reduction's since round 4)"""
+    a = _u64(a_jac); b = _u64(b_jac); out = np.zeros_like(a)
+    _check(lib().zkg_g1_add_pair29(_p(a), _p(b), C.c_size_t(a.size // 12), int(chain), _p(out)), "zkg_g1_add_pair29")
     return out.reshape(-1, 12)
 
 

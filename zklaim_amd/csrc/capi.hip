@@ -433,6 +433,46 @@ int zkg_g1_add_quad29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, in
     for (size_t i = 0; i < n; ++i) store_norm(out_jac + 12 * i, ho[i]);
     return ZKG_OK;
 }
+// the same hook for the pair form (fq29.hip.hpp xyzz29_add_pair): one pair of lanes per point pair, lane 0 holding (X, ZZ), lane 1 (Y, ZZZ)
+__global__ __launch_bounds__(64) void k_add_pair29(const XYZZ<Fq> *a, const XYZZ<Fq> *b, size_t n, int chain, XYZZ<Fq> *out) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1; const uint32_t r = threadIdx.x & 1;
+    if (i >= n) return;
+    auto half = [&](const XYZZ<Fq> &p) {
+        Half29 h = Half29::inf();
+        if (!p.is_inf()) { h.c0 = f29::to29(r ? p.y : p.x); h.c1 = f29::to29(r ? p.zzz : p.zz); }
+        return h;
+    };
+    Half29 x = half(a[i]); const Half29 y = half(b[i]);
+    xyzz29_add_pair(x, y, r);
+    for (int k = 0; k < chain; ++k) { const Half29 z = x; xyzz29_add_pair(x, y, r); xyzz29_add_pair(x, z, r); }
+    // both halves through a scratch record in LDS, then lane 0 converts and writes
+    __shared__ uint32_t rec[32][36];
+    uint32_t *w = rec[threadIdx.x >> 1] + 9 * r;
+    for (int j = 0; j < 9; ++j) { w[j] = x.c0.v[j]; w[18 + j] = x.c1.v[j]; }
+    __syncthreads();
+    if (r == 0) {
+        Fq29 c[4]; const uint32_t *q = rec[threadIdx.x >> 1]; uint32_t any = 0;
+        for (int k = 0; k < 4; ++k) for (int j = 0; j < 9; ++j) c[k].v[j] = q[9 * k + j];
+        for (int j = 0; j < 9; ++j) any |= c[2].v[j];
+        out[i] = any ? XYZZ<Fq>{f29::from29(c[0]), f29::from29(c[1]), f29::from29(c[2]), f29::from29(c[3])} : XYZZ<Fq>::inf().normalized();
+    }
+}
+int zkg_g1_add_pair29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac) {
+    REQUIRE_INIT();
+    if (!a_jac || !b_jac || !out_jac || chain < 0 || chain > 64) { set_error("zkg_g1_add_pair29: bad argument"); return ZKG_ERROR; }
+    if (!n) return ZKG_OK;
+    std::vector<G1> ha(n), hb(n), ho(n);
+    for (size_t i = 0; i < n; ++i) { ha[i] = load_norm_g1(a_jac + 12 * i).normalized(); hb[i] = load_norm_g1(b_jac + 12 * i).normalized(); }
+    ScopedDevBuf da, db, dout;
+    if (da.reserve(n * sizeof(G1)) || db.reserve(n * sizeof(G1)) || dout.reserve(n * sizeof(G1))) return ZKG_ERROR;
+    ZK_HIP(hipMemcpy(da.p, ha.data(), n * sizeof(G1), hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(db.p, hb.data(), n * sizeof(G1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_add_pair29, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, nullptr, da.as<G1>(), db.as<G1>(), n, chain, dout.as<G1>());
+    if (hipGetLastError() != hipSuccess) { set_error("zkg_g1_add_pair29: launch failed"); return ZKG_ERROR; }
+    ZK_HIP(hipMemcpy(ho.data(), dout.p, n * sizeof(G1), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) store_norm(out_jac + 12 * i, ho[i]);
+    return ZKG_OK;
+}
 int zkg_g2_sum(const uint64_t *points_jac, size_t count, uint64_t out_jac[24]) {
     G2 acc = G2::inf();
     for (size_t i = 0; i < count; ++i) acc.add(load_norm_g2(points_jac + 24 * i));

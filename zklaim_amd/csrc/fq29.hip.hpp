@@ -421,4 +421,71 @@ ZK_D void xyzz29_add_quad(XYZZ29q &a, const XYZZ29q &b, uint32_t q) {
     for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.y.v[i]), "+v"(a.zzz.v[i]));
 }
 
+
+// ---- the general addition shared by a PAIR of lanes (round 4: the bucket reduction's chains) ---------------------------------------------------------
+// The quad form above is bound by ISSUE, not latency (tools/r4_quad_chain.sh: 2.8 us of issue per wavefront-addition however many wavefronts
+// share the SIMD): four lanes run 16 products for the 14 an addition needs, and moving operands between them (135 VOP3 selects, 99 DPP moves, 27
+// ds_bpermute) costs as much again as the products.  Here lane 0 of a pair OWNS (X, ZZ) of every point and lane 1 owns (Y, ZZZ): the
+// first two rounds of the addition are then the SAME code in both lanes on their own registers —
+//     m0 = c0 * c1',  m1 = c0' * c1        (lane 0: U1, U2;  lane 1: S1, S2)          D = m1 - m0       (P;  R)
+//     sq = D^2,  zz = c1 * c1'             (PP, ZZ12;  RR, ZZZ12)
+// — round 3 runs in lane 0 only (PPP = P PP, Q = U1 PP; lane 1 repeats it on its own values and drops the result), and round 4 is one
+// paired stream again (lane 0: ZZ3 = ZZ12 PP, ZZZ3 = ZZZ12 PPP;  lane 1: R T, S1 PPP) after four 9-word exchanges (PPP and T to lane 1, RR
+// and ZZZ12 to lane 0) and a fifth that brings ZZZ3 home.  14 useful products in four paired streams per lane, 45 DPP moves and 54 one-condition selects
+// per addition: about half the quad form's issue per addition at the same depth.  Invariants and value bounds as XYZZ29q; infinity: a lane's
+// second coordinate (ZZ resp. ZZZ) all zero — both lanes see it without an exchange.
+struct Half29 {
+    Fq29 c0, c1;                                                  // lane 0: X, ZZ;  lane 1: Y, ZZZ
+    ZK_D bool is_inf() const { uint32_t o = 0; for (int i = 0; i < 9; ++i) o |= c1.v[i]; return o == 0; }
+    static ZK_D Half29 inf() { Half29 r; r.c0 = r.c1 = Fq29::zero(); return r; }
+};
+// the partner lane's copy (DPP quad_perm [1, 0, 3, 2]).  The two wait states a DPP read wants behind the VALU write of its source are
+// spelled out: the sources are usually the last writes of a generated product stream, which the compiler's hazard pass cannot see into.
+ZK_D Fq29 pair_swap29(const Fq29 &a) {
+    Fq29 t = a, r;
+    asm volatile("s_nop 1" : "+v"(t.v[0]), "+v"(t.v[1]), "+v"(t.v[2]), "+v"(t.v[3]), "+v"(t.v[4]), "+v"(t.v[5]), "+v"(t.v[6]), "+v"(t.v[7]), "+v"(t.v[8]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)t.v[i], 0xB1, 0xf, 0xf, true);
+    return r;
+}
+ZK_D Fq29 pair_pick29(bool second, const Fq29 &a, const Fq29 &b) { Fq29 r; for (int i = 0; i < 9; ++i) r.v[i] = second ? b.v[i] : a.v[i]; return r; }
+// a += b.  r: this lane's place in its pair (0 or 1).  Every branch is uniform across the pair (both lanes see the same infinity and
+// equality verdicts), so both lanes of a pair are active at every exchange; callers keep pairs whole inside divergent code.
+ZK_D void xyzz29_add_pair(Half29 &a, const Half29 &b, uint32_t r) {
+    using namespace f29;
+    if (b.is_inf()) return;
+    if (a.is_inf()) { a = b; return; }
+    const bool second = r != 0;
+    Fq29 m0, m1; mul2(m0, m1, a.c0, b.c1, b.c0, a.c1);                       // < 1.04 each
+    const Fq29 D = norm(sub(m1, S2_1, m0));                                   // P resp. R, < 3.1
+    const uint32_t zero_mine = is_zero_mod_p(D) ? 1u : 0u;
+    uint32_t zero_other; { uint32_t t = zero_mine; asm volatile("s_nop 1" : "+v"(t)); zero_other = (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0xB1, 0xf, 0xf, true); }
+    const bool p_zero = second ? zero_other != 0 : zero_mine != 0, r_zero = second ? zero_mine != 0 : zero_other != 0;
+    if (__builtin_expect(p_zero, 0)) {
+        if (r_zero) {                                                          // a == b: the doubling, on the 32-bit path (rare); both lanes rebuild the whole point
+            const Fq29 o0 = pair_swap29(a.c0), o1 = pair_swap29(a.c1);
+            XYZZ<Fq> t = {from29(second ? o0 : a.c0), from29(second ? a.c0 : o0), from29(second ? o1 : a.c1), from29(second ? a.c1 : o1)};
+            t = t.dbl();
+            a.c0 = to29((second ? t.y : t.x).normalized()); a.c1 = to29((second ? t.zzz : t.zz).normalized());
+        } else a = Half29::inf();
+        return;
+    }
+    Fq29 sq, zz; mul2(sq, zz, D, D, a.c1, b.c1);                              // PP, ZZ12 resp. RR, ZZZ12: < 1.06, 1.01
+    Fq29 t0, t1; mul2(t0, t1, D, sq, m0, sq);                                 // lane 0: PPP, Q (< 1.02, 1.01); lane 1: unused
+    const Fq29 ppp_in = pair_swap29(t0), rr_in = pair_swap29(sq);             // lane 1 receives PPP, lane 0 receives RR
+    const Fq29 X3 = norm(sub(rr_in, S4_3, add(t0, dbl(t1))));                 // lane 0: RR - PPP - 2Q + 4p < 5.1
+    const Fq29 T = sub(t1, S6_1, X3);                                         // lane 0: Q - X3 + 6p < 7.1, limbs below 2^30.6
+    const Fq29 t_in = pair_swap29(T), zzz12_in = pair_swap29(zz);             // lane 1 receives T, lane 0 receives ZZZ12
+    Fq29 n0, n1;
+    mul2(n0, n1, pair_pick29(second, zz, D), pair_pick29(second, sq, t_in), pair_pick29(second, zzz12_in, m0), pair_pick29(second, t0, ppp_in));
+    // lane 0: ZZ3 = ZZ12 PP, ZZZ3 = ZZZ12 PPP;  lane 1: R T, S1 PPP
+    const Fq29 zzz3_in = pair_swap29(n1);                                     // lane 1 receives ZZZ3
+    const Fq29 Y3 = norm(sub(n0, S2_1, n1));                                  // lane 1: R T - S1 PPP + 2p < 3.2
+    a.c0 = pair_pick29(second, X3, Y3);
+    a.c1 = pair_pick29(second, n0, zzz3_in);
+    // executed here, the whole pair active (see xyzz29_add_quad: a caller that only uses one lane's sum must not get these moves sunk into its branch)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.c0.v[i]), "+v"(a.c1.v[i]));
+}
+
 }  // namespace zk

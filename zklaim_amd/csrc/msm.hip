@@ -823,6 +823,88 @@ __global__ __launch_bounds__(RedGeom<Fq>::THREADS) void k_bucket_reduce29(const 
     }
 }
 
+// ---- 7''. the same reduction with every addition shared by a PAIR of lanes (fq29.hip.hpp xyzz29_add_pair): the quad kernel above is bound by
+//      the quad addition's issue (2.8 us per wavefront-addition: 16 lane-products and as many operand moves again for the 14 products an addition
+//      needs), a pair spends about half of that per addition at the same depth.  128 logical lanes = 256 threads, one wavefront per SIMD; same
+//      chunks, same chain (running sums, suffix scan, two trees), same two results per chunk as k_bucket_reduce29.
+ZK_D Half29 lds_load_half29(const LdsPoint29 *p, uint32_t r) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + 9 * r;
+    Half29 h;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { h.c0.v[i] = w[i]; h.c1.v[i] = w[18 + i]; }
+    return h;
+}
+ZK_D void lds_store_half29(LdsPoint29 *p, const Half29 &h, uint32_t r) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(p) + 9 * r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w[i] = h.c0.v[i]; w[18 + i] = h.c1.v[i]; }
+}
+template <bool IN29> ZK_D Half29 load_half29(const void *X_, uint32_t i, uint32_t B, uint32_t r) {
+    if (i >= B) return Half29::inf();
+    if constexpr (IN29) {                                                        // this lane's two coordinates of the 29-bit record
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Bucket29 *>(X_) + i) + 9 * r;
+        Half29 h;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { h.c0.v[j] = w[j]; h.c1.v[j] = w[18 + j]; }
+        return h;
+    } else {                                                                     // canonical XYZZ<Fq> (a table launch's folded buckets): two conversions per lane
+        const Fq *f = reinterpret_cast<const Fq *>(reinterpret_cast<const XYZZ<Fq> *>(X_) + i);
+        const Fq c0 = f[r], c1 = f[2 + r];
+        if (c1.is_zero()) return Half29::inf();
+        Fq29 to; for (int j = 0; j < 9; ++j) to.v[j] = f29::TO[j];
+        Half29 h; f29::mul2(h.c0, h.c1, f29::unpack(c0), to, f29::unpack(c1), to);
+        return h;
+    }
+}
+template <int RED_L_LOG, bool IN29>
+__global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(const void *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
+                                                                             size_t in_set_stride, size_t out_set_stride) {
+    constexpr int RED_LANES = RedGeom<Fq>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
+    extern __shared__ unsigned char red_smem[];
+    LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * RED_LANES points
+    const uint32_t t = threadIdx.x >> 1, r = threadIdx.x & 1;             // logical lane, place in its pair
+    const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
+    const size_t elem = IN29 ? sizeof(Bucket29) : sizeof(XYZZ<Fq>);
+    const void *X = reinterpret_cast<const char *>(buckets) + (blockIdx.y * in_set_stride + (size_t)w * B) * elem;
+    out += blockIdx.y * out_set_stride;
+    const uint32_t base = ch * RED_CHUNK + t * RED_L;
+    Half29 run = Half29::inf(), T0 = Half29::inf();
+    Half29 cur = load_half29<IN29>(X, base + RED_L - 1, B, r);
+    for (int j = RED_L - 1; j >= 1; --j) {
+        const Half29 nxt = load_half29<IN29>(X, base + j - 1, B, r);     // the next bucket arrives under the two additions
+        xyzz29_add_pair(run, cur, r);
+        xyzz29_add_pair(T0, run, r);
+        cur = nxt;
+    }
+    xyzz29_add_pair(run, cur, r);
+    Half29 Q = run;                                                      // inclusive suffix scan of the lane sums over logical lanes
+    for (uint32_t d = 1; d < RED_LANES; d <<= 1) {
+        lds_store_half29(sh + t, Q, r);
+        __syncthreads();
+        if (t + d < RED_LANES) xyzz29_add_pair(Q, lds_load_half29(sh + t + d, r), r);
+        __syncthreads();
+    }
+    const Half29 P = Q;                                                  // logical lane 0: total of the chunk
+    lds_store_half29(sh + t, t >= 1 ? Q : Half29::inf(), r); lds_store_half29(sh + RED_LANES + t, T0, r);
+    __syncthreads();
+    for (uint32_t d = RED_LANES / 2; d >= 1; d >>= 1) {
+        if (t < d) { Half29 a = lds_load_half29(sh + t, r); xyzz29_add_pair(a, lds_load_half29(sh + t + d, r), r); lds_store_half29(sh + t, a, r); }
+        else if (t >= RED_LANES / 2 && t < RED_LANES / 2 + d) {
+            const uint32_t u = RED_LANES + (t - RED_LANES / 2);
+            Half29 a = lds_load_half29(sh + u, r); xyzz29_add_pair(a, lds_load_half29(sh + u + d, r), r); lds_store_half29(sh + u, a, r);
+        }
+        __syncthreads();
+    }
+    if (t == 0) lds_store_half29(sh + 1, P, r);                          // (slot 1 is free once the trees are through)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        XYZZ<Fq> E = store_point29(sh[0].p);
+        for (int i = 0; i < RED_L_LOG; ++i) E = E.dbl();                 // * RED_L (RED_L_LOG doublings, once per workgroup: the 32-bit path)
+        E.add(store_point29(sh[RED_LANES].p));
+        out[2 * (size_t)blockIdx.x] = store_point29(sh[1].p); out[2 * (size_t)blockIdx.x + 1] = E.normalized();
+    }
+}
+
 // ---- 7b. per-window tables: all W windows weigh the same, so their bucket sets are summed bucket-wise before the one reduction.
 //      A workgroup takes FOLD_B buckets: its 256 threads load one accumulator each (window-major, so a wavefront reads FOLD_B
 //      consecutive buckets of one window), then an LDS tree over the windows — ceil(log2 W) levels instead of a W-long chain, the upper
@@ -1171,8 +1253,20 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         if (reduce29) {
             const size_t lds = 2 * RG::LANES * sizeof(LdsPoint29);
             const void *rin = red_in; XYZZ<Fq> *rout = reinterpret_cast<XYZZ<Fq> *>(gr.red_out.p);
+            static const bool red_quad = getenv("ZKG_REDUCE_QUAD") != nullptr;                            // A/B switch: round 3's quad kernel
             auto launch_red = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
-            if (out29) {
+            auto launch_redp = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
+            if (!red_quad) {
+                if (out29) {
+                    if (red_l_log == RED_L_LOG_LARGE) launch_redp(k_bucket_reduce29p<RED_L_LOG_LARGE, true>);
+                    else if (red_l_log == RED_L_LOG_SMALL) launch_redp(k_bucket_reduce29p<RED_L_LOG_SMALL, true>);
+                    else launch_redp(k_bucket_reduce29p<RED_L_LOG_TINY, true>);
+                } else {
+                    if (red_l_log == RED_L_LOG_LARGE) launch_redp(k_bucket_reduce29p<RED_L_LOG_LARGE, false>);
+                    else if (red_l_log == RED_L_LOG_SMALL) launch_redp(k_bucket_reduce29p<RED_L_LOG_SMALL, false>);
+                    else launch_redp(k_bucket_reduce29p<RED_L_LOG_TINY, false>);
+                }
+            } else if (out29) {
                 if (red_l_log == RED_L_LOG_LARGE) launch_red(k_bucket_reduce29<RED_L_LOG_LARGE, true>);
                 else if (red_l_log == RED_L_LOG_SMALL) launch_red(k_bucket_reduce29<RED_L_LOG_SMALL, true>);
                 else launch_red(k_bucket_reduce29<RED_L_LOG_TINY, true>);
