@@ -933,6 +933,12 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_bucket_fold(const XYZZ<F> *buc
     if (t < FB && b < B) out[b] = sh[t].normalized();
 }
 
+// 1 / x for the in-lane batched normalisations below.  Fq: through the 29-bit safegcd (f29::inverse: ~70 products' worth against the ~380 of the
+// Fermat chain behind Fq::inverse(); two conversions); Fq2: the same on its norm.
+template <class F> ZK_D F inverse_fast(const F &x) {
+    if constexpr (std::is_same<F, Fq>::value) return f29::from29(f29::inverse(f29::to29(x.normalized())));
+    else { const Fq d = inverse_fast<Fq>(x.c0.sqr() + x.c1.sqr()); return F{x.c0 * d, (x.c1 * d).neg()}; }      // (c0 - c1 u) / (c0^2 + c1^2), as Fq2::inverse()
+}
 // levels j+1 .. j+K of a window table from level j: level j+l = 2^(c l) * level j.  One lane walks a point through its K x c doublings in
 // XYZZ and normalises the K results with ONE inversion (Montgomery's trick over their ZZZ): a level per launch spent 80 % of its
 // time in the 380-product Fermat inversion of each point.  out points at level j+1; levels are n entries apart.
@@ -955,7 +961,7 @@ __global__ __launch_bounds__(256) void k_table_levels(const Affine<F> *in, Affin
     F pre[K], run = F::one();
 #pragma unroll
     for (int l = 0; l < K; ++l) { pre[l] = run; if (!zzz[l].is_zero()) run = run * zzz[l]; }
-    F inv = run.inverse();
+    F inv = inverse_fast(run);
 #pragma unroll
     for (int l = K - 1; l >= 0; --l) {
         if (l >= levels) continue;
@@ -1761,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, cons
     F pre[FB_K], run = F::one();
 #pragma unroll
     for (int k = 0; k < FB_K; ++k) { pre[k] = run; if (!zzz[k].is_zero()) run = run * zzz[k]; }
-    F inv = run.inverse();
+    F inv = inverse_fast(run);
 #pragma unroll
     for (int k = FB_K - 1; k >= 0; --k) {
         if (i0 + k >= n) continue;
