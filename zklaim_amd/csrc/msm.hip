@@ -1262,7 +1262,9 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
             static const bool red_quad = getenv("ZKG_REDUCE_QUAD") != nullptr;                            // A/B switch: round 3's quad kernel
             auto launch_red = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
             auto launch_redp = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
-            if (!red_quad) {
+            // one bucket per logical lane (a table launch's folded set: the prover): the chain is 17 steps either way and the quad kernel's two
+            // wavefronts per SIMD hide its LDS rounds a little better (90 against 94 us); the pair form is for the long chains
+            if (!red_quad && red_l_log != RED_L_LOG_TINY) {
                 if (out29) {
                     if (red_l_log == RED_L_LOG_LARGE) launch_redp(k_bucket_reduce29p<RED_L_LOG_LARGE, true>);
                     else if (red_l_log == RED_L_LOG_SMALL) launch_redp(k_bucket_reduce29p<RED_L_LOG_SMALL, true>);
