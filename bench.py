@@ -18,6 +18,12 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# Under torch.distributed.run the process also holds RCCL's streams.  HIP maps streams onto 4 hardware queues by default; the piece-wise step
+# drives four streams of its own (caller's, copy, record conversion, high-priority sort), and with RCCL's beside them two of those land on one
+# queue: the upload then serialises with the compute it should hide (measured on one rank: 2.02 -> 2.67 ms per step; 8 or 16 queues restore
+# 2.02, tools/r4_dist_ab.sh).  Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
+if "WORLD_SIZE" in os.environ:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 SEED = 0x5A4B4C41494D0000
 LOGN = 20
