@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256) void k_digits_c(const uint32_t *scalars, const
     uint32_t carry = 0, own = g.w0, slot = 0;
 #pragma unroll
     for (int w = 0; w < WT; ++w) {
-        constexpr int dummy = 0; (void)dummy;
         const int off = w * C, limb = off >> 5, sh = off & 31;
         uint32_t v = limb < 8 ? f.v[limb < 8 ? limb : 7] >> sh : 0u;
         if (sh + C > 32 && limb + 1 < 8) v |= f.v[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
