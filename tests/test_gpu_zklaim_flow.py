@@ -121,6 +121,11 @@ def test_c_caller_links_the_seam(zkg, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr[-500:])
     assert out.returncode == 0 and "seam demo ok" in out.stdout
+    # the same program as an issuer that keeps nothing on the GPU (ZKG_SEAM_ISSUER_ONLY): libsnark_prove then loads the key from ctx->pk's
+    # bytes, as a prover that received the blob would — same results
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ZKG_SEAM_ISSUER_ONLY="1"))
+    print(out.stdout, out.stderr[-500:])
+    assert out.returncode == 0 and "seam demo ok" in out.stdout
 
 
 def test_c_caller_of_the_multi_gpu_entry_points(zkg, tmp_path):
