@@ -178,6 +178,44 @@ __global__ __launch_bounds__(256) void k_digits_c(const uint32_t *scalars, const
     }
 }
 
+// ... and four consecutive scalars per thread (no gather list, n a multiple of 4, every window owned): a window's four digits leave as ONE 16-byte
+// store per lane — 1 KiB per wavefront instead of four 256-byte stores (the kernel is bound by its store instructions: 16.7 M four-byte stores at 2^20)
+template <int C>
+__global__ __launch_bounds__(256) void k_digits_c4(const uint32_t *scalars, size_t n, int mont, MsmGeom g, uint32_t *digits, ZeroList zl) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) for (size_t z = i; z < zl.words[k]; z += lanes) zl.p[k][z] = 0;
+    if (4 * i >= n) return;
+    Fr f[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * (4 * i + q));
+        const uint4 a = p[0], b = p[1];
+        f[q].v[0] = a.x; f[q].v[1] = a.y; f[q].v[2] = a.z; f[q].v[3] = a.w; f[q].v[4] = b.x; f[q].v[5] = b.y; f[q].v[6] = b.z; f[q].v[7] = b.w;
+        if (mont) f[q] = f[q].from_mont();
+    }
+    constexpr int WT = (SCALAR_BITS + C - 1) / C;
+    constexpr uint32_t B = 1u << (C - 1), MASK = (1u << C) - 1;
+    uint32_t carry[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+        const int off = w * C, limb = off >> 5, sh = off & 31;
+        uint32_t code[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t v = limb < 8 ? f[q].v[limb < 8 ? limb : 7] >> sh : 0u;
+            if (sh + C > 32 && limb + 1 < 8) v |= f[q].v[limb + 1 < 8 ? limb + 1 : 7] << (32 - sh);
+            const uint32_t raw = (v & MASK) + carry[q];
+            const bool neg = raw > B;
+            const uint32_t d = neg ? (1u << C) - raw : raw;
+            carry[q] = neg ? 1u : 0u;
+            code[q] = d ? (d << 1) | (neg ? 1u : 0u) : 0u;
+        }
+        *reinterpret_cast<uint4 *>(digits + (size_t)w * n + 4 * i) = make_uint4(code[0], code[1], code[2], code[3]);
+    }
+}
+
 // ---- 2. per-(window, slice) histogram in LDS ---------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t *digits, size_t n, uint32_t B, uint32_t S, uint32_t slice_len, uint32_t *hist) {
     extern __shared__ uint32_t lds_u32[];
@@ -275,6 +313,15 @@ __global__ __launch_bounds__(1024) void k_rx_count(const uint32_t *digits, size_
     __syncthreads();
     size_t lo = (size_t)sl * RX_SLICE, hi = lo + RX_SLICE < n ? lo + RX_SLICE : n;
     const uint32_t *d = digits + (size_t)w * n;
+    if ((n & 3) == 0) {                                                   // rows 16-byte aligned: four digits per load
+        for (size_t i = lo + 4 * t; i < hi; i += 4096) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(d + i);     // (hi - lo is a multiple of 4 with n)
+            if (q.x) atomicAdd(&c[((q.x >> 1) - 1) >> fbits], 1u);
+            if (q.y) atomicAdd(&c[((q.y >> 1) - 1) >> fbits], 1u);
+            if (q.z) atomicAdd(&c[((q.z >> 1) - 1) >> fbits], 1u);
+            if (q.w) atomicAdd(&c[((q.w >> 1) - 1) >> fbits], 1u);
+        }
+    } else
     for (size_t i = lo + t; i < hi; i += 1024) { uint32_t code = d[i]; if (code) atomicAdd(&c[((code >> 1) - 1) >> fbits], 1u); }
     __syncthreads();
     if (t < CB && c[t]) atomicAdd(&cnt[w * CB + t], c[t]);
@@ -308,12 +355,23 @@ __global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, siz
     size_t lo = (size_t)sl * RX_SLICE, hi = lo + RX_SLICE < n ? lo + RX_SLICE : n;
     const uint32_t *d = digits + (size_t)w * n;
     uint32_t code[RX_SLICE / 1024];                                  // this thread's 16 digits stay in registers between the two passes
+    // which element of the slice is this thread's j-th: four consecutive ones per 16-byte load when the rows are aligned (n a multiple of 4)
+    const bool vec = (n & 3) == 0;
+    auto elem = [&](uint32_t j) -> size_t { return vec ? lo + 4 * (size_t)t + (size_t)(j >> 2) * 4096 + (j & 3) : lo + t + (size_t)j * 1024; };
+    if (vec) {
 #pragma unroll
-    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) {
-        size_t i = lo + t + (size_t)j * 1024;
-        code[j] = i < hi ? d[i] : 0;
-        if (code[j]) atomicAdd(&c[((code[j] >> 1) - 1) >> fbits], 1u);
+        for (uint32_t j = 0; j < RX_SLICE / 1024; j += 4) {
+            const size_t i = elem(j);
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (i < hi) q = *reinterpret_cast<const uint4 *>(d + i);
+            code[j] = q.x; code[j + 1] = q.y; code[j + 2] = q.z; code[j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) { const size_t i = elem(j); code[j] = i < hi ? d[i] : 0; }
     }
+#pragma unroll
+    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) if (code[j]) atomicAdd(&c[((code[j] >> 1) - 1) >> fbits], 1u);
     __syncthreads();
     if (t < CB) off[t] = c[t];                                       // exclusive scan of the bin counts (Hillis-Steele), off[CB] = entries of the slice
     __syncthreads();
@@ -332,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, siz
 #pragma unroll
     for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) {
         if (!code[j]) continue;
-        uint32_t i = (uint32_t)(lo + t + (size_t)j * 1024), b = (code[j] >> 1) - 1, k = b >> fbits;
+        uint32_t i = (uint32_t)elem(j), b = (code[j] >> 1) - 1, k = b >> fbits;
         uint32_t pos = off[k] + atomicAdd(&cur[k], 1u);
         stage[pos] = ((b & fmask) << (32 - fbits)) | (i << 1) | (code[j] & 1u);
     }
@@ -1390,7 +1448,11 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
         }
         static const bool generic_digits = getenv("ZKG_DIGITS_GENERIC") != nullptr;                     // A/B switch
         const dim3 dg((unsigned)((n0 + 255) / 256));                                                     // n >= 1 (msm_job_launch)
-        if (!generic_digits && g0.c == 16) hipLaunchKernelGGL(k_digits_c<16>, dg, dim3(256), 0, s, d_scalars, d_gather, n0, (int)mont, g0, digits, zl);
+        const bool four = !d_gather && (n0 & 3) == 0 && g0.w0 == 0 && g0.ws == 1 && g0.W == g0.Wt;      // every window stored, rows 16-byte aligned
+        const dim3 dg4((unsigned)((n0 / 4 + 255) / 256));
+        if (!generic_digits && four && g0.c == 16) hipLaunchKernelGGL(k_digits_c4<16>, dg4, dim3(256), 0, s, d_scalars, n0, (int)mont, g0, digits, zl);
+        else if (!generic_digits && four && g0.c == 12) hipLaunchKernelGGL(k_digits_c4<12>, dg4, dim3(256), 0, s, d_scalars, n0, (int)mont, g0, digits, zl);
+        else if (!generic_digits && g0.c == 16) hipLaunchKernelGGL(k_digits_c<16>, dg, dim3(256), 0, s, d_scalars, d_gather, n0, (int)mont, g0, digits, zl);
         else if (!generic_digits && g0.c == 12) hipLaunchKernelGGL(k_digits_c<12>, dg, dim3(256), 0, s, d_scalars, d_gather, n0, (int)mont, g0, digits, zl);
         else hipLaunchKernelGGL(k_digits, dg, dim3(256), 0, s, d_scalars, d_gather, n0, (int)mont, g0, digits, zl);
     }
