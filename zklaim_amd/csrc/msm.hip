@@ -962,6 +962,28 @@ __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(con
     }
 }
 
+// ---- 7b'. the fold of a table launch's bucket rows on the 29-bit records: a pair of lanes per bucket adds its W rows in sequence (xyzz29_add_pair; rows
+//      without entries were never written and are skipped by their length), Bucket29 in, Bucket29 out — the accumulation stores its accumulators as they
+//      are and the reduction loads the folded set as it is: no conversion anywhere between the gathers and the chunk results.
+__global__ __launch_bounds__(256) void k_bucket_fold29(const Bucket29 *buckets, const uint32_t *counts, uint32_t W, uint32_t B, Bucket29 *out) {
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 1, r = threadIdx.x & 1;
+    if (b >= B) return;                                                         // (B is even: pairs stay whole)
+    Half29 acc = Half29::inf();
+    uint32_t w = 0;
+    while (w < W && !counts[(size_t)w * B + b]) ++w;
+    Half29 cur = w < W ? load_half29<true>(buckets + (size_t)w * B, b, B, r) : Half29::inf();
+    while (w < W) {
+        uint32_t nw = w + 1;
+        while (nw < W && !counts[(size_t)nw * B + b]) ++nw;
+        const Half29 nxt = nw < W ? load_half29<true>(buckets + (size_t)nw * B, b, B, r) : Half29::inf();   // the next row arrives under the addition
+        xyzz29_add_pair(acc, cur, r);
+        cur = nxt; w = nw;
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + b) + 9 * r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { o[i] = acc.c0.v[i]; o[18 + i] = acc.c1.v[i]; }
+}
+
 // ---- 7b. per-window tables: all W windows weigh the same, so their bucket sets are summed bucket-wise before the one reduction.
 //      A workgroup takes FOLD_B buckets: its 256 threads load one accumulator each (window-major, so a wavefront reads FOLD_B
 //      consecutive buckets of one window), then an LDS tree over the windows — ceil(log2 W) levels instead of a W-long chain, the upper
@@ -1191,7 +1213,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if (gr.heavy_items.reserve(ns * max_items * sizeof(HeavyItem)) || gr.heavy_buckets.reserve(ns * max_heavy * sizeof(HeavyBucket)) ||
         gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
         bucket_buf.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
-        (gr.table && gr.folded.reserve(ns * (size_t)g.B * sizeof(XYZZ<F>))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
+        (gr.table && gr.folded.reserve(ns * (size_t)g.B * std::max(sizeof(XYZZ<F>), sizeof(Bucket29)))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
     // (gr.heavy_counters: cleared by the job's k_digits)
     XYZZ<F> *buckets = bucket_buf.as<XYZZ<F>>();
     ViewSet<F> views;
@@ -1226,7 +1248,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     }
     static const bool red32_env = getenv("ZKG_REDUCE_32") != nullptr;
     // plain G1 set on the 29-bit kernels: the buckets stay 29-bit records from the accumulation to the reduction
-    const bool out29 = use29 && stride29 == 0 && !gr.table && !red32_env;
+    static const bool fold32_env = getenv("ZKG_FOLD_32") != nullptr;                                       // A/B switch: table launches keep canonical XYZZ buckets and the 32-bit fold
+    // ... and so do a lone table set's (the prover's H query: accumulate -> k_bucket_fold29 -> reduce, all on the records)
+    // — where the rows are few (8 after the row merge of the large tables: a bucket's rows are added in sequence, 4 us each; a one-payload key's 22
+    // rows of 2048 buckets keep the 32-bit fold, a tree over the rows: 0.75 against 0.83 ms per proof)
+    const bool out29 = use29 && !red32_env && (stride29 == 0 ? !gr.table : (gr.table && ns == 1 && g.W <= 8 && !fold32_env));
     const int resume = job->resume ? 1 : 0;
     MsmJob *owner = job->bucket_owner ? job->bucket_owner : job;                // (whose buckets these are)
     if (resume && !(out29 && owner->last_out29)) { set_error("msm: a piece can only continue 29-bit buckets"); return ZKG_ERROR; }
@@ -1239,7 +1265,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         const char *e_ba = getenv("ZKG_ACCUM_BA"), *e_k = getenv("ZKG_BA_K");
         const int ba_levels = e_ba ? std::max(0, std::min((int)ba::MAX_LEVELS, atoi(e_ba))) : 0;
         const int ba_k = e_k ? std::max(2, std::min(32, atoi(e_k) & ~1)) : 16;
-        if (use29 && out29 && !resume && ba_levels > 0 && n_entries_max >= 4096) {
+        if (use29 && out29 && stride29 == 0 && !resume && ba_levels > 0 && n_entries_max >= 4096) {
             const int R = ba_levels, K = ba_k;
             const size_t per_wg = (size_t)ba::THREADS * K, words_start = n_entries_max / 32 + 2;
             size_t stride[ba::MAX_LEVELS + 1] = {0}, plane_words = 0, grid1 = 0;
@@ -1303,7 +1329,15 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         return ZKG_OK;
     }
     const XYZZ<F> *red_in = buckets; size_t in_stride = L.buckets;
-    if (gr.table) {
+    bool folded29 = false;
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        if (gr.table && out29) {
+            hipLaunchKernelGGL(k_bucket_fold29, dim3((2 * g.B + 255) / 256), dim3(256), 0, s, reinterpret_cast<const Bucket29 *>(buckets), job->counts.as<uint32_t>(), g.W, g.B,
+                               gr.folded.as<Bucket29>());
+            red_in = gr.folded.as<XYZZ<F>>(); in_stride = L.folded; folded29 = true;
+        }
+    }
+    if (gr.table && !folded29) {
         uint32_t slots = 1; while (slots < g.W && slots < 32) slots <<= 1;                // window slots per workgroup: W rounded up to a power of two (<= 32)
         uint32_t fold_b_log = 0; while ((FOLD_THREADS >> (fold_b_log + 1)) >= slots) ++fold_b_log;
         hipLaunchKernelGGL(k_bucket_fold<F>, dim3((g.B + (1u << fold_b_log) - 1) >> fold_b_log, ns), dim3(FOLD_THREADS), FOLD_THREADS * sizeof(LdsPoint<F>), s,
