@@ -331,6 +331,10 @@ def test_host_scalars_pieces_equal_the_resident_msm(zkg, oracle, n):
         assert np.array_equal(exp, oracle.msm_g1(bases, sc))
     assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_sc.data_ptr(), n), exp)
     assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), sc.ctypes.data, n), exp)          # pageable host memory
+    if n == (1 << 19) + 777:                                                     # scalars handed over in Montgomery form (a witness vector as libff keeps it)
+        sc_m = np.ascontiguousarray(zkg.field_op(1, 4, sc))
+        h_m = torch.from_numpy(sc_m.view(np.int64)).pin_memory()
+        assert np.array_equal(zkg.msm_g1_host_scalars(d_bases.data_ptr(), h_m.data_ptr(), n, scalars_mont=True), exp)
     # a third of the scalars equal (one giant bucket per window, in every piece), some zero, r - 1, a duplicated base and a base at infinity
     sc2 = sc.copy(); rng = np.random.default_rng(n); kind = rng.integers(0, 100, n)
     sc2[kind < 33] = sc2[0]; sc2[(kind >= 33) & (kind < 40)] = 0; sc2[n - 1] = limbs(R - 1); sc2[n // 2] = limbs(R - 1)
