@@ -75,6 +75,7 @@ struct ProverSlot {
     struct HShardRun { int device = 0; zk::MsmJob *job = nullptr; zk::DevBuf scalars; };
     std::vector<HShardRun> h_runs; uint64_t h_epoch = 0;                       // h_epoch: the sharding (zkg_crs::h_epoch) these were made for
     zk::OnesSum ones_g1, ones_g2;               // flat sums of the bases whose witness element is one: (A, B_g1, L) and B_g2, on streams of their own
+    std::vector<uint8_t> scan_tags; std::vector<uint32_t> scan_idx; std::vector<uint64_t> scan_vals;    // a dense witness rewritten as tags + listed values (witness_to_sparse)
     hipStream_t stream_o = nullptr;
     Helper helper;
     hipEvent_t ev[20]; bool ev_ok = false, ready = false;
@@ -963,6 +964,43 @@ static int prove_finish(zkg_crs *crs, ProverSlot &S, uint8_t *proof_out, size_t 
     return ZKG_OK;
 }
 
+// A dense witness whose variables are mostly bits (a credential circuit's: 97 %) is cheaper to SCAN on the host pool than to upload: 32 bytes per
+// variable over PCIe (0.58 ms at 2^20 variables) against a read of the same bytes from host memory in 32 chunks (~0.2 ms) and an upload of one tag byte per
+// variable plus the listed values — the sparse form zkg_groth16_prove_sparse takes, built here for callers of the dense entry point.  Gives up (false: the
+// dense upload) as soon as more than 1/16 of the variables are not bits, and below 2^19 variables, where waking the pool costs what the upload did
+// (tools/r4_dense_scan_ab.sh, dense upload -> scan: 37 payloads / 2^20 domain 3.78 -> 3.53 ms, 8 payloads 1.29 -> 1.32, 2 payloads 0.78 -> 0.83).
+// ZKG_DENSE_UPLOAD=1 switches it off (A/B).
+static bool witness_to_sparse(const uint64_t *w, size_t n, std::vector<uint8_t> &tags, std::vector<uint32_t> &idx, std::vector<uint64_t> &vals) {
+    static const bool off = getenv("ZKG_DENSE_UPLOAD") != nullptr;
+    if (off || n < ((size_t)1 << 19)) return false;
+    const Fr one_fr = Fr::one();
+    uint64_t one[4]; memcpy(one, one_fr.v, 32);
+    const size_t cap = n / 16;
+    tags.resize(n);
+    const int chunks = (int)std::min<size_t>(32, n / 32768 + 1);
+    std::vector<std::vector<uint32_t>> found((size_t)chunks);
+    std::atomic<bool> over{false};
+    uint8_t *t = tags.data();
+    zk::host_parallel_for(chunks, [&](int ch) {
+        const size_t lo = n * (size_t)ch / (size_t)chunks, hi = n * (size_t)(ch + 1) / (size_t)chunks;
+        std::vector<uint32_t> &f = found[(size_t)ch];
+        for (size_t v = lo; v < hi; ++v) {
+            const uint64_t *e = w + 4 * v;
+            if ((e[0] | e[1] | e[2] | e[3]) == 0) t[v] = 0;
+            else if (e[0] == one[0] && e[1] == one[1] && e[2] == one[2] && e[3] == one[3]) t[v] = 1;
+            else { t[v] = 2; f.push_back((uint32_t)v); if (f.size() > cap) { over.store(true); return; } }
+        }
+    });
+    if (over.load()) return false;
+    size_t total = 0;
+    for (auto &f : found) total += f.size();
+    if (total > cap) return false;
+    idx.clear(); idx.reserve(total);
+    for (auto &f : found) idx.insert(idx.end(), f.begin(), f.end());
+    vals.resize(4 * total);
+    for (size_t i = 0; i < total; ++i) memcpy(&vals[4 * i], w + 4 * (size_t)idx[i], 32);
+    return true;
+}
 static int groth16_prove_impl(const zkg_crs *crs_, const uint64_t *witness, const uint64_t r_[4], const uint64_t s_[4], int check_satisfied,
                               uint8_t *proof_out, size_t *proof_len) {
     zkg_crs *crs = const_cast<zkg_crs *>(crs_);
@@ -970,7 +1008,9 @@ static int groth16_prove_impl(const zkg_crs *crs_, const uint64_t *witness, cons
     SlotLease lease(crs);
     if (!lease.ok()) return ZKG_ERROR;
     ProverSlot &S = lease.S();
-    WitnessSrc W; W.dense = witness;
+    WitnessSrc W;
+    if (witness_to_sparse(witness, crs->n, S.scan_tags, S.scan_idx, S.scan_vals)) { W.tags = S.scan_tags.data(); W.idx = S.scan_idx.data(); W.vals = S.scan_vals.data(); W.count = S.scan_idx.size(); }
+    else W.dense = witness;
     if (prove_enqueue(crs, S, W, r_, s_, check_satisfied != 0)) { slot_drain(crs, S); return ZKG_ERROR; }
     return prove_finish(crs, S, proof_out, proof_len);
 }
