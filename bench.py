@@ -482,7 +482,7 @@ def main():
                     "same_result": bool(np.array_equal(r2, result)), "what": "zkg_msm_g1_dev: bases AND scalars resident in HBM when the timed call starts (the headline of rounds 1-3)",
                     "accumulation_kernel": {"kernel_ms": round(res_kern_ms, 4), "launches": res_launches, "achieved_GBps": round(BYTES_PER_POINT * n / (res_kern_ms * 1e-3) / 1e9, 3) if res_kern_ms > 0 else None,
                                             "frac_of_hbm_peak": round(BYTES_PER_POINT * n / (res_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if res_kern_ms > 0 else None,
-                                            "note": "k_bucket_accum29 as ONE launch with the chip to itself; in the headline step its three launches share the chip with the next piece's digit sort (roofline.kernel_ms)"},
+                                            "note": "k_bucket_accum29 as ONE launch with the chip to itself; in the headline step its launches (one per piece) share the chip with the next piece's digit sort (roofline.kernel_ms)"},
                     "one_upload_then_resident_call": {"ms_per_step": stats_ms(each_u), "GBps_algorithmic_median": round(BYTES_PER_POINT * n / float(np.median(each_u)) / 1e9, 3),
                                                       "same_result": bool(np.array_equal(r3, result))}}
 

@@ -48,6 +48,11 @@
 #include <cstring>
 #include <mutex>
 
+// Register cap of one kernel.  gfx90a and later have one 512-entry file per lane for VGPRs and AGPRs, and LLVM doubles the attribute's
+// value there before it compares it with the budget ("amdgpu-num-vgpr" counts the unified file): half the wanted number of VGPRs goes in.
+#define ZK_VGPR_CAP(n) __attribute__((amdgpu_num_vgpr((n) / 2)))
+static constexpr int ACC29_VGPRS = 192;
+
 namespace zk {
 
 static constexpr int SCALAR_BITS = 255;      // r < 2^254; one extra bit absorbs the signed-digit carry
@@ -121,11 +126,18 @@ ZK_D uint32_t bits_at(const uint32_t v[8], uint32_t off, uint32_t c) {
     return (uint32_t)(x >> sh) & ((1u << c) - 1);
 }
 
+// The digit sort's kernels raise their wavefronts' issue priority: in a piece-wise job they share SIMDs with the accumulation of the piece
+// before (k_bucket_accum29 leaves them the registers, ACC29_VGPRS), whose older, multiply-bound wavefronts would otherwise win every
+// arbitration — k_digits_c4 took 113 ... 183 us beside an accumulation, 10 us alone.  The sort is 5 % of the step's instructions and on its critical path.
+ZK_D void sort_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+
+
 // digit code: 0 = no contribution; otherwise ((bucket + 1) << 1) | negative, bucket = |d| - 1
 // The job's first kernel also clears the counters its later kernels accumulate into (coarse-bin counts, class histogram, heavy-bucket
 // counters): three hipMemsetAsync fill launches per job were three more dependent launches on a proof's critical path.
 struct ZeroList { uint32_t *p[4]; uint32_t words[4]; };
 __global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, const uint32_t *gather, size_t n, int mont, MsmGeom g, uint32_t *digits, ZeroList zl) {
+    sort_wave_priority();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
 #pragma unroll
@@ -151,6 +163,7 @@ __global__ __launch_bounds__(256) void k_digits(const uint32_t *scalars, const u
 // 96 MB of traffic cost).
 template <int C>
 __global__ __launch_bounds__(256) void k_digits_c(const uint32_t *scalars, const uint32_t *gather, size_t n, int mont, MsmGeom g, uint32_t *digits, ZeroList zl) {
+    sort_wave_priority();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
 #pragma unroll
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(256) void k_digits_c(const uint32_t *scalars, const
 // store per lane — 1 KiB per wavefront instead of four 256-byte stores (the kernel is bound by its store instructions: 16.7 M four-byte stores at 2^20)
 template <int C>
 __global__ __launch_bounds__(256) void k_digits_c4(const uint32_t *scalars, size_t n, int mont, MsmGeom g, uint32_t *digits, ZeroList zl) {
+    sort_wave_priority();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
 #pragma unroll
@@ -301,12 +315,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_place(const uint32_t *digits, 
 //      WRITE_SIZE for a 64 MiB list), so here no pass scatters single words to global memory: pass 1 splits a 16K-point slice into the
 //      64 coarse bins of its window inside LDS and writes each bin's run contiguously; pass 2 takes one (window, coarse bin), sorts its
 //      ~n/64 entries by the remaining bucket bits inside LDS and writes the final list — and the bucket counts and offsets — in order.
-static constexpr uint32_t RX_MAX_CBITS = 10, RX_MAX_CB = 1u << RX_MAX_CBITS, RX_SLICE = 16384, RX_FINE_MAX = 8192, RX_BIN_AVG = 4096;
+static constexpr uint32_t RX_MAX_CBITS = 10, RX_MAX_CB = 1u << RX_MAX_CBITS, RX_SLICE = 16384, RX_PER_THREAD = 16, RX_FINE_MAX = 8192, RX_BIN_AVG = 4096;
 // temporary entry between the passes: fine bucket (fbits) in the top bits | point index << 1 | sign below.  cbits: log2 of the coarse bins
 // per window, chosen on the host so that a bin averages <= 4096 entries, half of what the second pass holds in LDS (measured: 1365 ...
 // 8192 all within 2 %).  The top window of a 254-bit scalar populates only 38 % of its buckets, so its bins are 2.65x as full and go to
 // the streamed path of k_rx_fine (rx_fine_big_bin).
 __global__ __launch_bounds__(1024) void k_rx_count(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, uint32_t *cnt) {
+    sort_wave_priority();
     __shared__ uint32_t c[RX_MAX_CB];
     const uint32_t sl = blockIdx.x, w = blockIdx.y, t = threadIdx.x, CB = 1u << cbits;
     if (t < CB) c[t] = 0;
@@ -328,6 +343,7 @@ __global__ __launch_bounds__(1024) void k_rx_count(const uint32_t *digits, size_
 }
 // exclusive scan of the W * 2^cbits bin counts (<= 16384 of them, 16 per thread) -> bin start positions; base[nbins] = number of entries
 __global__ __launch_bounds__(1024) void k_rx_scan(const uint32_t *cnt, uint32_t nbins, uint32_t *base, uint32_t *cursor, uint32_t *grand_total) {
+    sort_wave_priority();
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, per = (nbins + 1023) / 1024, lo = t * per, hi = lo + per < nbins ? lo + per : nbins;
     uint32_t sum = 0;
@@ -344,23 +360,29 @@ __global__ __launch_bounds__(1024) void k_rx_scan(const uint32_t *cnt, uint32_t 
     for (uint32_t i = lo; i < hi; ++i) { base[i] = run; cursor[i] = 0; run += cnt[i]; }
     if (t == 1023) { base[nbins] = part[1023]; *grand_total = part[1023]; }
 }
-__global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, const uint32_t *base, uint32_t *cursor,
-                                                      uint32_t *tmp) {
+// T threads per workgroup take a slice of 16 T digits.  T = 1024 (16K-digit slices, 64 KiB of LDS) when the sort has the chip to itself; T = 512 for
+// the sorts of a piece-wise job, which run BESIDE the accumulation of the piece before: two wavefronts per SIMD of 56 registers fit into what
+// k_bucket_accum29 leaves free (ACC29_VGPRS), four do not.
+template <int T>
+__global__ __launch_bounds__(T) void k_rx_scatter(const uint32_t *digits, size_t n, uint32_t fbits, uint32_t cbits, const uint32_t *base, uint32_t *cursor,
+                                                   uint32_t *tmp) {
+    sort_wave_priority();
     extern __shared__ uint32_t lds_u32[];
+    constexpr uint32_t SLICE = RX_PER_THREAD * T;
     const uint32_t CB = 1u << cbits;
-    uint32_t *stage = lds_u32, *c = lds_u32 + RX_SLICE, *off = c + RX_MAX_CB, *gb = off + RX_MAX_CB + 1, *cur = gb + RX_MAX_CB;
+    uint32_t *stage = lds_u32, *c = lds_u32 + SLICE, *off = c + RX_MAX_CB, *gb = off + RX_MAX_CB + 1, *cur = gb + RX_MAX_CB;
     const uint32_t sl = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-    if (t < CB) c[t] = 0;
+    for (uint32_t b = t; b < CB; b += T) c[b] = 0;
     __syncthreads();
-    size_t lo = (size_t)sl * RX_SLICE, hi = lo + RX_SLICE < n ? lo + RX_SLICE : n;
+    size_t lo = (size_t)sl * SLICE, hi = lo + SLICE < n ? lo + SLICE : n;
     const uint32_t *d = digits + (size_t)w * n;
-    uint32_t code[RX_SLICE / 1024];                                  // this thread's 16 digits stay in registers between the two passes
+    uint32_t code[RX_PER_THREAD];                                    // this thread's 16 digits stay in registers between the two passes
     // which element of the slice is this thread's j-th: four consecutive ones per 16-byte load when the rows are aligned (n a multiple of 4)
     const bool vec = (n & 3) == 0;
-    auto elem = [&](uint32_t j) -> size_t { return vec ? lo + 4 * (size_t)t + (size_t)(j >> 2) * 4096 + (j & 3) : lo + t + (size_t)j * 1024; };
+    auto elem = [&](uint32_t j) -> size_t { return vec ? lo + 4 * (size_t)t + (size_t)(j >> 2) * (4 * T) + (j & 3) : lo + t + (size_t)j * T; };
     if (vec) {
 #pragma unroll
-        for (uint32_t j = 0; j < RX_SLICE / 1024; j += 4) {
+        for (uint32_t j = 0; j < RX_PER_THREAD; j += 4) {
             const size_t i = elem(j);
             uint4 q = make_uint4(0, 0, 0, 0);
             if (i < hi) q = *reinterpret_cast<const uint4 *>(d + i);
@@ -368,27 +390,30 @@ __global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, siz
         }
     } else {
 #pragma unroll
-        for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) { const size_t i = elem(j); code[j] = i < hi ? d[i] : 0; }
+        for (uint32_t j = 0; j < RX_PER_THREAD; ++j) { const size_t i = elem(j); code[j] = i < hi ? d[i] : 0; }
     }
 #pragma unroll
-    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) if (code[j]) atomicAdd(&c[((code[j] >> 1) - 1) >> fbits], 1u);
+    for (uint32_t j = 0; j < RX_PER_THREAD; ++j) if (code[j]) atomicAdd(&c[((code[j] >> 1) - 1) >> fbits], 1u);
     __syncthreads();
-    if (t < CB) off[t] = c[t];                                       // exclusive scan of the bin counts (Hillis-Steele), off[CB] = entries of the slice
+    // exclusive scan of the bin counts (Hillis-Steele; a thread owns bins t and t + T: CB <= 1024 <= 2 T), off[CB] = entries of the slice
+    const uint32_t b0 = t, b1 = t + T;
+    if (b0 < CB) off[b0] = c[b0];
+    if (b1 < CB) off[b1] = c[b1];
     __syncthreads();
     for (uint32_t dd = 1; dd < CB; dd <<= 1) {
-        uint32_t x = (t < CB && t >= dd) ? off[t - dd] : 0;
+        const uint32_t x0 = (b0 < CB && b0 >= dd) ? off[b0 - dd] : 0, x1 = (b1 < CB && b1 >= dd) ? off[b1 - dd] : 0;
         __syncthreads();
-        if (t < CB) off[t] += x;
+        if (b0 < CB) off[b0] += x0;
+        if (b1 < CB) off[b1] += x1;
         __syncthreads();
     }
-    if (t == CB - 1) off[CB] = off[t];
+    if (t == 0) off[CB] = off[CB - 1];
     __syncthreads();
-    if (t < CB) off[t] -= c[t];
-    if (t < CB) { gb[t] = c[t] ? base[w * CB + t] + atomicAdd(&cursor[w * CB + t], c[t]) : 0; cur[t] = 0; }
+    for (uint32_t b = t; b < CB; b += T) { off[b] -= c[b]; gb[b] = c[b] ? base[w * CB + b] + atomicAdd(&cursor[w * CB + b], c[b]) : 0; cur[b] = 0; }
     __syncthreads();
     const uint32_t fmask = (1u << fbits) - 1;
 #pragma unroll
-    for (uint32_t j = 0; j < RX_SLICE / 1024; ++j) {
+    for (uint32_t j = 0; j < RX_PER_THREAD; ++j) {
         if (!code[j]) continue;
         uint32_t i = (uint32_t)elem(j), b = (code[j] >> 1) - 1, k = b >> fbits;
         uint32_t pos = off[k] + atomicAdd(&cur[k], 1u);
@@ -397,13 +422,14 @@ __global__ __launch_bounds__(1024) void k_rx_scatter(const uint32_t *digits, siz
     __syncthreads();
     // runs go out contiguously, one wavefront per bin at a time (consecutive lanes -> consecutive addresses)
     const uint32_t wave = t >> 6, lane = t & 63;
-    for (uint32_t k = wave; k < CB; k += 16) {
+    for (uint32_t k = wave; k < CB; k += T / 64) {
         const uint32_t a = off[k], b = off[k + 1], g = gb[k];
         for (uint32_t p = a + lane; p < b; p += 64) tmp[g + (p - a)] = stage[p];
     }
 }
 // shared by the two second-pass kernels: exclusive scan of the FB <= 512 counters (Hillis-Steele in LDS), counts / offsets to global
 ZK_D void rx_fine_offsets(uint32_t *cf, uint32_t *of, uint32_t FB, uint32_t t, uint32_t start, size_t gb0, uint32_t *counts, uint32_t *offsets) {
+    const uint32_t T = blockDim.x;                                    // FB <= 512 <= T
     if (t < FB) of[t] = cf[t];
     __syncthreads();
     for (uint32_t d = 1; d < FB; d <<= 1) {
@@ -414,7 +440,7 @@ ZK_D void rx_fine_offsets(uint32_t *cf, uint32_t *of, uint32_t FB, uint32_t t, u
     }
     if (t < FB) of[t] -= cf[t];
     __syncthreads();
-    for (uint32_t f = t; f < FB; f += 1024) { counts[gb0 + f] = cf[f]; offsets[gb0 + f] = start + of[f]; }
+    for (uint32_t f = t; f < FB; f += T) { counts[gb0 + f] = cf[f]; offsets[gb0 + f] = start + of[f]; }
 }
 // A bin with more entries than LDS holds, i.e. many equal digits (a 0/1 witness without ZKG_SCALARS_MOSTLY_BITS, adversarial input, the
 // partly filled top window): the workgroup streams the bin twice; lanes of a wavefront that hold the same fine bucket share one LDS atomic
@@ -422,12 +448,12 @@ ZK_D void rx_fine_offsets(uint32_t *cf, uint32_t *of, uint32_t FB, uint32_t t, u
 // more launch per sort whose workgroups all returned at once for uniform scalars.)
 ZK_D void rx_fine_big_bin(const uint32_t *tmp, uint32_t fbits, uint32_t start, uint32_t cnt, size_t gb0, uint32_t *cf, uint32_t *of, uint32_t *cur, uint32_t *counts,
                           uint32_t *offsets, uint32_t *sorted) {
-    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1, t = threadIdx.x;
+    const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1, t = threadIdx.x, T = blockDim.x;
     const bool giant = cnt > 8 * RX_FINE_MAX;                         // many equal digits; below that (a dense top window) plain atomics are faster
     if (!giant) {
-        for (uint32_t p = t; p < cnt; p += 1024) atomicAdd(&cf[tmp[start + p] >> sh], 1u);
+        for (uint32_t p = t; p < cnt; p += T) atomicAdd(&cf[tmp[start + p] >> sh], 1u);
     } else
-    for (uint32_t p0 = 0; p0 < cnt; p0 += 1024) {
+    for (uint32_t p0 = 0; p0 < cnt; p0 += T) {
         uint32_t p = p0 + t; bool live = p < cnt; uint32_t f = live ? tmp[start + p] >> sh : 0;
         while (__any(live)) {
             uint32_t lf = __shfl(f, __ffsll((long long)__ballot(live)) - 1, 64);
@@ -438,10 +464,10 @@ ZK_D void rx_fine_big_bin(const uint32_t *tmp, uint32_t fbits, uint32_t start, u
     __syncthreads();
     rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
     if (!giant) {
-        for (uint32_t p = t; p < cnt; p += 1024) { uint32_t e = tmp[start + p], f = e >> sh; sorted[start + of[f] + atomicAdd(&cur[f], 1u)] = e & low; }
+        for (uint32_t p = t; p < cnt; p += T) { uint32_t e = tmp[start + p], f = e >> sh; sorted[start + of[f] + atomicAdd(&cur[f], 1u)] = e & low; }
         return;
     }
-    for (uint32_t p0 = 0; p0 < cnt; p0 += 1024) {
+    for (uint32_t p0 = 0; p0 < cnt; p0 += T) {
         uint32_t p = p0 + t; bool live = p < cnt; uint32_t e = live ? tmp[start + p] : 0, f = e >> sh;
         while (__any(live)) {
             uint32_t lf = __shfl(f, __ffsll((long long)__ballot(live)) - 1, 64);
@@ -455,34 +481,37 @@ ZK_D void rx_fine_big_bin(const uint32_t *tmp, uint32_t fbits, uint32_t start, u
 }
 // second pass, one workgroup per (window, coarse bin).  A bin whose entries fit LDS (every bin of uniformly random scalars): entries stay in
 // registers between the count and the placement, the sorted bin is assembled in LDS and written out in order
-__global__ __launch_bounds__(1024) void k_rx_fine(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts, uint32_t *offsets,
-                                                   uint32_t *sorted) {
+// (T threads: 1024, or 512 beside a running accumulation — see k_rx_scatter; the bin size the workgroup holds is the same)
+template <int T>
+__global__ __launch_bounds__(T) void k_rx_fine(const uint32_t *tmp, uint32_t fbits, uint32_t cbits, uint32_t B, const uint32_t *base, uint32_t *counts, uint32_t *offsets,
+                                                uint32_t *sorted) {
+    sort_wave_priority();
     extern __shared__ uint32_t lds_u32[];
     const uint32_t FB = 1u << fbits, sh = 32 - fbits, low = (1u << sh) - 1;
     uint32_t *bufB = lds_u32, *cf = bufB + RX_FINE_MAX, *of = cf + FB, *cur = of + FB;       // 64 KiB + counters: two workgroups per CU
     const uint32_t cb = blockIdx.x, w = blockIdx.y, t = threadIdx.x, bin = (w << cbits) + cb;
     const uint32_t start = base[bin], cnt = base[bin + 1] - start;
     const size_t gb0 = (size_t)w * B + (size_t)cb * FB;
-    for (uint32_t f = t; f < FB; f += 1024) { cf[f] = 0; cur[f] = 0; }
+    for (uint32_t f = t; f < FB; f += T) { cf[f] = 0; cur[f] = 0; }
     __syncthreads();
     if (cnt > RX_FINE_MAX) { rx_fine_big_bin(tmp, fbits, start, cnt, gb0, cf, of, cur, counts, offsets, sorted); return; }     // (uniform across the workgroup)
-    uint32_t ent[RX_FINE_MAX / 1024];
+    uint32_t ent[RX_FINE_MAX / T];
 #pragma unroll
-    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
-        uint32_t p = t + j * 1024;
+    for (uint32_t j = 0; j < RX_FINE_MAX / T; ++j) {
+        uint32_t p = t + j * T;
         ent[j] = p < cnt ? tmp[start + p] : 0xffffffffu;
         if (p < cnt) atomicAdd(&cf[ent[j] >> sh], 1u);
     }
     __syncthreads();
     rx_fine_offsets(cf, of, FB, t, start, gb0, counts, offsets);
 #pragma unroll
-    for (uint32_t j = 0; j < RX_FINE_MAX / 1024; ++j) {
-        if (t + j * 1024 >= cnt) continue;
+    for (uint32_t j = 0; j < RX_FINE_MAX / T; ++j) {
+        if (t + j * T >= cnt) continue;
         uint32_t e = ent[j], f = e >> sh;
         bufB[of[f] + atomicAdd(&cur[f], 1u)] = e & low;
     }
     __syncthreads();
-    for (uint32_t p = t; p < cnt; p += 1024) sorted[start + p] = bufB[p];
+    for (uint32_t p = t; p < cnt; p += T) sorted[start + p] = bufB[p];
 }
 
 // Heavy threshold, computed on the device from the real list lengths: a lane walks its bucket's list alone (~7 us per G1
@@ -502,6 +531,7 @@ ZK_D uint32_t heavy_threshold_dev(const uint32_t *offsets, size_t total_buckets,
 
 // ---- 5. bucket order by descending length (classes 0..heavy_t, heavy_t+1 = heavy) ------------------------
 __global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, const uint32_t *offsets, size_t total, uint32_t *class_hist) {
+    sort_wave_priority();
     __shared__ uint32_t h[HEAVY_T_MAX + 2];
     const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
     const uint32_t t = threadIdx.x, nc = heavy_t + 2;
@@ -514,6 +544,7 @@ __global__ __launch_bounds__(1024) void k_class_hist(const uint32_t *counts, con
 }
 // in place: start position of every class, longest first (one 1024-thread workgroup; class c is scanned at position nc - 1 - c)
 __global__ __launch_bounds__(1024) void k_class_scan(uint32_t *class_hist, const uint32_t *offsets, size_t total) {
+    sort_wave_priority();
     __shared__ uint32_t part[1024];
     const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1), nc = heavy_t + 2, t = threadIdx.x;
     // HEAVY_T_MAX + 2 = 1026 classes at most: thread t takes positions 2t and 2t + 1 of the reversed order
@@ -531,6 +562,7 @@ __global__ __launch_bounds__(1024) void k_class_scan(uint32_t *class_hist, const
     if (2 * t + 1 < nc) class_hist[nc - 2 - 2 * t] = before + v0;
 }
 __global__ __launch_bounds__(1024) void k_order_place(const uint32_t *counts, const uint32_t *offsets, size_t total, uint32_t *class_cursor, uint32_t *order) {
+    sort_wave_priority();
     __shared__ uint32_t h[HEAVY_T_MAX + 2];
     const uint32_t heavy_t = heavy_threshold_dev(offsets, total, 1);
     const uint32_t t = threadIdx.x, nc = heavy_t + 2;
@@ -606,14 +638,18 @@ ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
     for (int j = 0; j < 5; ++j) dst[j] = src[j];
     return o;
 }
-// WAVES: wavefronts per SIMD the register allocation aims for (2: 204 registers, no spill; 3: 168 registers and a 232-byte spill frame)
+// WAVES: wavefronts per SIMD the register allocation aims for (2: no spill in the loop; 3: 168 registers and a 232-byte spill frame)
+// ACC29_VGPRS: left to itself the allocator spends all 256 registers two wavefronts per SIMD allow (253 for OUT29: loop-invariant constants
+// parked in registers) and nothing else fits on the SIMD beside them.  Capped at 192 the addition's instruction stream is the same (2 281
+// instructions, the spills all on the exceptional doubling path), and 128 registers per SIMD stay free: the digit sort of the NEXT piece of a
+// piece-wise job (msm_g1_host_scalars) runs on the same compute units at once instead of waiting for accumulation workgroups to retire.
 // level_stride != 0: `bases` is a per-window table (level w = 2^(c w) P_i, level_stride records apart) and a bucket reads its window's level
 // OUT29: the buckets are Bucket29 records (the plain G1 path: the reduction reads them without conversion) instead of canonical XYZZ<Fq>
 // (table launches: the fold in between works on 32-bit limbs).  resume (OUT29 only): the buckets hold the sums of the job's earlier pieces
 // (piece-wise multi-exponentiation, msm_g1_host_scalars): a lane continues its bucket's accumulator, an empty list leaves it alone, and a
 // heavy bucket's old value joins its parts in k_heavy_merge.
 template <int WAVES, bool OUT29>
-__global__ __launch_bounds__(256, WAVES) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+__global__ __launch_bounds__(256, WAVES) ZK_VGPR_CAP(ACC29_VGPRS) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
                                                          size_t lanes, void *buckets_, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L, int resume) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
@@ -1497,9 +1533,19 @@ static int sort_digits(MsmJob *job, const uint32_t *d_scalars, bool mont, const 
         uint32_t *cnt = job->rx_meta.as<uint32_t>(), *base = cnt + nbins, *cursor = base + nbins + 1, *tmp = job->rx_tmp.as<uint32_t>();
         hipLaunchKernelGGL(k_rx_count, dim3(S1, g.W), dim3(1024), 0, s, digits, n, fbits, cbits, cnt);
         hipLaunchKernelGGL(k_rx_scan, dim3(1), dim3(1024), 0, s, cnt, nbins, base, cursor, offsets + total);
-        hipLaunchKernelGGL(k_rx_scatter, dim3(S1, g.W), dim3(1024), (RX_SLICE + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
-        hipLaunchKernelGGL(k_rx_fine, dim3(CB, g.W), dim3(1024), (RX_FINE_MAX + 3 * (1u << fbits)) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
-                           job->sorted.as<uint32_t>());
+        // (a sort on a stream of its own runs beside an accumulation: half-size workgroups fit into the registers that one leaves free)
+        static const int wg_env = getenv("ZKG_SORT_WG") ? atoi(getenv("ZKG_SORT_WG")) : 0;                 // A/B switch: 512 / 1024 everywhere
+        const bool half = (wg_env ? wg_env == 512 : job->sort_stream != nullptr) && fbits <= 9;           // (k_rx_fine's scan: one fine bucket per thread)
+        if (half) {
+            const uint32_t S2 = (uint32_t)((n + 512 * RX_PER_THREAD - 1) / (512 * RX_PER_THREAD));
+            hipLaunchKernelGGL(k_rx_scatter<512>, dim3(S2, g.W), dim3(512), (512 * RX_PER_THREAD + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
+            hipLaunchKernelGGL(k_rx_fine<512>, dim3(CB, g.W), dim3(512), (RX_FINE_MAX + 3 * (1u << fbits)) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
+                               job->sorted.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(k_rx_scatter<1024>, dim3(S1, g.W), dim3(1024), (RX_SLICE + 4 * RX_MAX_CB + 8) * 4, s, digits, n, fbits, cbits, base, cursor, tmp);
+            hipLaunchKernelGGL(k_rx_fine<1024>, dim3(CB, g.W), dim3(1024), (RX_FINE_MAX + 3 * (1u << fbits)) * 4, s, tmp, fbits, cbits, g.B, base, counts, offsets,
+                               job->sorted.as<uint32_t>());
+        }
     } else {                                                                                    // one pass: histogram, scans, k_place
     hipLaunchKernelGGL(k_hist, dim3(S, g.W), dim3(SORT_THREADS), g.B * 4, s, digits, n, g.B, S, slice_len, hist);
     hipLaunchKernelGGL(k_colscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hist, g.B, S, total, counts);
@@ -1657,7 +1703,7 @@ int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2
 int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size_t n, bool mont, G1 *out, hipStream_t s) {
     if (n >= ((size_t)1 << 28)) { set_error("msm: at most 2^28 - 1 points per call"); return ZKG_ERROR; }
     if (!n) { *out = G1::inf(); return ZKG_OK; }
-    static const int max_pieces = getenv("ZKG_MSM_PIECES") ? std::max(1, std::min(8, atoi(getenv("ZKG_MSM_PIECES")))) : 3;        // tuning aid (1: one upload, one launch); measured 2 / 3 / 4 / 5 pieces: 2.25 / 2.19 / 2.27 / 2.41 ms at 2^20 points
+    static const int max_pieces = getenv("ZKG_MSM_PIECES") ? std::max(1, std::min(8, atoi(getenv("ZKG_MSM_PIECES")))) : 4;        // tuning aid (1: one upload, one launch); 2^20 points, sorts beside the accumulation (ACC29_VGPRS, sort_wave_priority): 3 / 4 / 5 pieces 1.99 / 1.94 / 2.02 ms (before: 2.19 / 2.27 / 2.41)
     static const bool no29 = getenv("ZKG_ACCUM_32") != nullptr || getenv("ZKG_REDUCE_32") != nullptr;
     const bool pieces = max_pieces > 1 && !no29 && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 23);
     if (n > ((size_t)1 << 23)) {                                                // huge: one upload, then the resident path's own 2^23-point pieces
@@ -1681,7 +1727,7 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
         if (msm_job_launch(&J, &set, 1, d_sc, n, mont, nullptr)) return ZKG_ERROR;
         return msm_job_finish(&J, out, nullptr);
     }
-    // piece boundaries: halves from the top, the lowest one split once more -> n/4, n/4, n/2 for three pieces
+    // piece boundaries: halves from the top, the lowest one split once more -> n/8, n/8, n/4, n/2 for four pieces
     size_t cut[9]; int P = max_pieces;
     cut[P] = n;
     for (int k = P - 1; k >= 1; --k) cut[k] = (cut[k + 1] / 2) & ~(size_t)255;
@@ -1698,7 +1744,8 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
     // Pieces alternate between two jobs — two sets of sort buffers, ONE set of buckets, all accumulations in order on the caller's stream —
     // and every piece's digit sort runs on a high-priority stream of its own beside the accumulation of the piece before it: the sort's
     // small dependent launches and single-workgroup scans stand a third of a step when alone and cost the accumulation little beside it
-    // (without the priority they crawl: k_rx_count 134 us instead of 11).  The bases' 29-bit records are made once for all pieces, on
+    // (without the priority they crawl: k_rx_count 134 us instead of 11; and they only run BESIDE it because the accumulation leaves a
+    // quarter of each SIMD's registers free and the sort's wavefronts raise their own issue priority — ACC29_VGPRS, sort_wave_priority).  The bases' 29-bit records are made once for all pieces, on
     // the side stream, under the first upload.
     static const bool two_jobs = getenv("ZKG_MSM_PIECES_ONE_STREAM") == nullptr;                          // A/B switch
     MsmJob &K = g_piece_job;
@@ -1928,8 +1975,10 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)k_rx_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_FINE_MAX + 3 * 1024) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (512 * RX_PER_THREAD + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_fine<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_FINE_MAX + 3 * 1024) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_rx_fine<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_FINE_MAX + 3 * 1024) * 4) == hipSuccess;
     return ok ? ZKG_OK : ZKG_ERROR;
 }
 void msm_release_all() {
