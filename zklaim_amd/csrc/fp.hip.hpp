@@ -24,6 +24,11 @@
 #define ZK_HD __host__ __device__ __forceinline__
 #define ZK_D __device__ __forceinline__
 
+// Issue priority of a wavefront (s_setprio, 0 .. 3).  A proof's kernels share compute units across streams: the witness multi-exponentiations
+// run beside the transforms and the H query's multi-exponentiation, which are the critical path.  The oldest wavefront wins the arbitration by
+// default; the kernels on the critical path raise theirs (2; the digit sort's small dependent launches 3) so that the work with slack waits.
+__device__ __forceinline__ void crit_wave_priority(int on) { if (on) __builtin_amdgcn_s_setprio(2); }
+
 namespace zk {
 
 struct FqParams {

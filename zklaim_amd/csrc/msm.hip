@@ -650,7 +650,9 @@ ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
 // heavy bucket's old value joins its parts in k_heavy_merge.
 template <int WAVES, bool OUT29>
 __global__ __launch_bounds__(256, WAVES) ZK_VGPR_CAP(ACC29_VGPRS) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
-                                                         size_t lanes, void *buckets_, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L, int resume) {
+                                                         size_t lanes, void *buckets_, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L, int flags /* 1: resume, 2: critical path */) {
+    crit_wave_priority(flags & 2);
+    const int resume = flags & 1;
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
     const uint32_t heavy_t = heavy_threshold_dev(offsets, L.buckets, 1);
@@ -871,7 +873,8 @@ ZK_D XYZZ<Fq> store_point29(const XYZZ29q &p) {
 }
 template <int RED_L_LOG, bool IN29>
 __global__ __launch_bounds__(RedGeom<Fq>::THREADS) void k_bucket_reduce29(const void *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
-                                                                          size_t in_set_stride, size_t out_set_stride) {
+                                                                          size_t in_set_stride, size_t out_set_stride, int critical) {
+    crit_wave_priority(critical);
     constexpr int RED_LANES = RedGeom<Fq>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
     LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * RED_LANES points
@@ -951,7 +954,8 @@ template <bool IN29> ZK_D Half29 load_half29(const void *X_, uint32_t i, uint32_
 }
 template <int RED_L_LOG, bool IN29>
 __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(const void *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
-                                                                             size_t in_set_stride, size_t out_set_stride) {
+                                                                             size_t in_set_stride, size_t out_set_stride, int critical) {
+    crit_wave_priority(critical);
     constexpr int RED_LANES = RedGeom<Fq>::LANES, RED_L = 1 << RED_L_LOG, RED_CHUNK = RED_LANES * RED_L;
     extern __shared__ unsigned char red_smem[];
     LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * RED_LANES points
@@ -1001,7 +1005,8 @@ __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(con
 // ---- 7b'. the fold of a table launch's bucket rows on the 29-bit records: a pair of lanes per bucket adds its W rows in sequence (xyzz29_add_pair; rows
 //      without entries were never written and are skipped by their length), Bucket29 in, Bucket29 out — the accumulation stores its accumulators as they
 //      are and the reduction loads the folded set as it is: no conversion anywhere between the gathers and the chunk results.
-__global__ __launch_bounds__(256) void k_bucket_fold29(const Bucket29 *buckets, const uint32_t *counts, uint32_t W, uint32_t B, Bucket29 *out) {
+__global__ __launch_bounds__(256) void k_bucket_fold29(const Bucket29 *buckets, const uint32_t *counts, uint32_t W, uint32_t B, Bucket29 *out, int critical) {
+    crit_wave_priority(critical);
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 1, r = threadIdx.x & 1;
     if (b >= B) return;                                                         // (B is even: pairs stay whole)
     Half29 acc = Half29::inf();
@@ -1215,6 +1220,7 @@ struct MsmJob {
     // piece-wise jobs (msm_g1_host_scalars): `resume` — this launch's accumulation continues the buckets of the launch before it;
     // `defer_reduce` — more pieces follow: no reduction, nothing copied back; `c_fixed` — every piece uses the whole job's window size
     bool resume = false, defer_reduce = false; bool last_out29 = false;
+    bool critical = false;                        // msm_job_set_critical: the accumulate / fold / reduce kernels raise their wavefronts' issue priority
     // a second job that alternates with this one over the pieces of one multi-exponentiation accumulates into THIS job's buckets
     MsmJob *bucket_owner = nullptr;
     // the digit sort may run on a stream of its own (high priority: its small kernels get the compute units an accumulation frees first);
@@ -1341,7 +1347,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
         auto launch29 = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
                                job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, (void *)buckets, gr.heavy_items.as<HeavyItem>(),
-                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L, resume);
+                               gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L, resume | (job->critical ? 2 : 0));
         };
         if (use29 && waves29 == 3) { if (out29) launch29(k_bucket_accum29<3, true>); else launch29(k_bucket_accum29<3, false>); }
         else if (use29) { if (out29) launch29(k_bucket_accum29<2, true>); else launch29(k_bucket_accum29<2, false>); }
@@ -1369,7 +1375,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     if constexpr (sizeof(F) == sizeof(Fq)) {
         if (gr.table && out29) {
             hipLaunchKernelGGL(k_bucket_fold29, dim3((2 * g.B + 255) / 256), dim3(256), 0, s, reinterpret_cast<const Bucket29 *>(buckets), job->counts.as<uint32_t>(), g.W, g.B,
-                               gr.folded.as<Bucket29>());
+                               gr.folded.as<Bucket29>(), job->critical ? 1 : 0);
             red_in = gr.folded.as<XYZZ<F>>(); in_stride = L.folded; folded29 = true;
         }
     }
@@ -1387,8 +1393,8 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
             const size_t lds = 2 * RG::LANES * sizeof(LdsPoint29);
             const void *rin = red_in; XYZZ<Fq> *rout = reinterpret_cast<XYZZ<Fq> *>(gr.red_out.p);
             static const bool red_quad = getenv("ZKG_REDUCE_QUAD") != nullptr;                            // A/B switch: round 3's quad kernel
-            auto launch_red = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
-            auto launch_redp = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out); };
+            auto launch_red = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(RG::THREADS), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out, job->critical ? 1 : 0); };
+            auto launch_redp = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out, job->critical ? 1 : 0); };
             // one bucket per logical lane (a table launch's folded set: the prover): the chain is 17 steps either way and the quad kernel's two
             // wavefronts per SIMD hide its LDS rounds a little better (90 against 94 us); the pair form is for the long chains
             if (!red_quad && red_l_log != RED_L_LOG_TINY) {
@@ -1573,6 +1579,8 @@ MsmJob *msm_job_create(hipStream_t s, bool own_stream, bool high_priority) {
     return j;
 }
 void msm_job_set_window(MsmJob *j, int c) { if (j) j->window_hint = c; }
+bool crit_priority_enabled() { static const bool on = !(getenv("ZKG_CRIT_PRIO") && atoi(getenv("ZKG_CRIT_PRIO")) == 0); return on; }
+void msm_job_set_critical(MsmJob *j, bool critical) { if (j) j->critical = critical && crit_priority_enabled(); }
 void msm_job_set_row_merge(MsmJob *j, uint32_t f) { if (j) j->merge_hint = f ? f : 1; }
 void msm_job_set_skewed(MsmJob *j, bool skewed) { if (j) j->one_pass_sort = skewed; }
 void msm_job_set_window_subset(MsmJob *j, uint32_t w0, uint32_t ws) { if (j) { j->w0 = w0; j->ws = ws ? ws : 1; } }

@@ -96,9 +96,11 @@ struct NttPassArgs29 {
     uint32_t post_scalar[9];
     uint32_t n_log, s0, R, cw_log, first, last, has_post_scalar, row_pad;      // row_pad: records of padding per LDS row
     uint32_t xcd_tiles;                                                        // tiles per XCD (0 = identity map)
+    uint32_t critical;                                                         // raise the wavefronts' issue priority (crit_wave_priority)
     size_t src_batch_stride, dst_batch_stride;      // elements between the vectors of a batch (blockIdx.y), in the units of src / dst
 };
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
+    crit_wave_priority((int)A.critical);
     extern __shared__ U4 smem[];
     Rec29 *lds = reinterpret_cast<Rec29 *>(smem);
     const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = CW + A.row_pad;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
 //      step instead of one per stage.  Limb bounds: stage q: x + t < 2^30, x + 2r - t < 1.5 x 2^30 (these feed stage q + 1's products: the
 //      stream takes limbs up to 2.5 x 2^30, tools/gen_mont_asm.py selftest_f29); stage q + 1: below 2.5 x 2^30.  An odd R ends with one radix-2 step.
 __global__ __launch_bounds__(256) void k_ntt_pass29_r4(NttPassArgs29 A) {
+    crit_wave_priority((int)A.critical);
     extern __shared__ U4 smem[];
     Rec29 *lds = reinterpret_cast<Rec29 *>(smem);
     const uint32_t rows = 1u << A.R, CW = 1u << A.cw_log, stride = CW + A.row_pad;
@@ -404,6 +407,9 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
             B.row_pad = pad29;
             static const bool xcd_map = !getenv("ZKG_NTT_XCD") || atoi(getenv("ZKG_NTT_XCD")) != 0;
             B.xcd_tiles = (xcd_map && tiles % 8 == 0) ? (uint32_t)(tiles / 8) : 0;
+            // the transforms are the prover's critical path at 2^20 (beside the witness multi-exponentiations); below, the G2 witness chain ends
+            // as late as the H query and raised priorities here cost more there (CRIT_PRIORITY_MIN_LOG)
+            B.critical = (crit_priority_enabled() && n >= CRIT_PRIORITY_MIN_LOG) ? 1u : 0u;
             static const int radix_force = getenv("ZKG_NTT_RADIX2") ? (atoi(getenv("ZKG_NTT_RADIX2")) ? 2 : 4) : 0;          // A/B switch
             if (radix_force ? radix_force == 4 : large) {
                 const unsigned threads4 = (unsigned)std::min<size_t>(256, std::max<size_t>(64, rows * CW / 4));             // one thread per four rows of a column

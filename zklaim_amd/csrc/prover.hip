@@ -181,7 +181,8 @@ ZK_D Fr row_dot_short(const uint32_t *rp, const uint32_t *col, const Fr *val, co
 __global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
                                                     const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
                                                     const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
-                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC) {
+                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, int critical) {
+    crit_wave_priority(critical);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, 
 }
 
 // the same on a step_radix2_domain: Z(g x_i) takes big/small distinct values on the first big points and one on the rest
-__global__ __launch_bounds__(256) void k_pointwise_h_step(Fr *aA, const Fr *aB, const Fr *aC, size_t m, size_t big, const Fr *zinv, uint32_t period_mask, Fr zinv_small) {
+__global__ __launch_bounds__(256) void k_pointwise_h_step(Fr *aA, const Fr *aB, const Fr *aC, size_t m, size_t big, const Fr *zinv, uint32_t period_mask, Fr zinv_small, int critical) {
+    crit_wave_priority(critical);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     Fr zi = i < big ? zinv[i & period_mask] : zinv_small;
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(256) void k_scatter_full(const uint32_t *idx, const
 }
 
 // H_tmp = (aA . aB - aC) * Zinv  (divide_by_Z_on_coset fused with the pointwise product)
-__global__ __launch_bounds__(256) void k_pointwise_h(Fr *aA, const Fr *aB, const Fr *aC, size_t m, Fr zinv) {
+__global__ __launch_bounds__(256) void k_pointwise_h(Fr *aA, const Fr *aB, const Fr *aC, size_t m, Fr zinv, int critical) {
+    crit_wave_priority(critical);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     aA[i] = ((aA[i] * aB[i] - aC[i]) * zinv).normalized();
@@ -342,6 +345,7 @@ struct WitnessSrc {                           // dense: n x 4 limbs; or sparse: 
 };
 // phase 1 of r1cs_to_qap_witness_map: z = [1 | w] resident and split, the three mat-vecs, the satisfiability flag
 static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want_flag) {
+    const int crit = (crit_priority_enabled() && crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG)) ? 1 : 0;   // (see ntt_run_ex)
     hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
     Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -372,7 +376,7 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                        crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(),
-                       z, crs->C, crs->l, m, aA, aB, aC);
+                       z, crs->C, crs->l, m, aA, aB, aC, crit);
     if (crs->n_long)
         hipLaunchKernelGGL(k_r1cs_long, dim3((crs->n_long + 3) / 4), dim3(256), 0, s, crs->long_rows.as<uint32_t>(), crs->n_long,
                            crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
@@ -388,6 +392,7 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
 }
 // phase 2: the seven transforms and the pointwise step -> coefficients_for_H in aA
 static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
+    const int crit = (crit_priority_enabled() && crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG)) ? 1 : 0;   // (see ntt_run_ex)
     hipStream_t s = S.stream;
     const size_t m = crs->m;
     Fr *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -399,7 +404,7 @@ static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
         const Fr *fused = crs->coset_over_m.as<Fr>();
         if (ntt_run_ex(crs->dom, aA, true, nullptr, fused, nullptr, s, scr, 3, 0, nullptr, crs->coset_over_m29.p)) return ZKG_ERROR;
         if (ntt_run_ex(crs->dom, aA, false, nullptr, nullptr, nullptr, s, scr, 3)) return ZKG_ERROR;
-        hipLaunchKernelGGL(k_pointwise_h, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset);
+        hipLaunchKernelGGL(k_pointwise_h, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, crs->z_inv_coset, crit);
         if (ntt_run_ex(crs->dom, aA, true, nullptr, crs->dom->icoset_post.as<Fr>(), nullptr, s, scr)) return ZKG_ERROR;   // icosetFFT -> coefficients_for_H[0..m)
     } else {
         // step_radix2_domain: the same four steps, each transform a fold/unfold pass around a 2^a and a 2^b radix-2 transform
@@ -407,7 +412,7 @@ static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
         if (step_ntt_run(sd, aA, true, false, s, scr, 3, m)) return ZKG_ERROR;                     // iFFT  x3
         if (step_ntt_run(sd, aA, false, true, s, scr, 3, m)) return ZKG_ERROR;                     // cosetFFT x3
         hipLaunchKernelGGL(k_pointwise_h_step, dim3(grid_m), dim3(256), 0, s, aA, aB, aC, m, sd->shape.big, sd->zinv.as<Fr>(),
-                           (uint32_t)(sd->shape.big / sd->shape.small - 1), sd->zinv_small);
+                           (uint32_t)(sd->shape.big / sd->shape.small - 1), sd->zinv_small, crit);
         if (step_ntt_run(sd, aA, true, true, s, scr, 1, m)) return ZKG_ERROR;                      // icosetFFT
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[2], s);
@@ -450,6 +455,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
              hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
             msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w); msm_job_set_window(S.job_h, crs->H_query.c);
+            msm_job_set_critical(S.job_h, crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG));                              // the H query's multi-exponentiation ends the proof; the witness jobs beside it have slack
             // H: sixteen windows in eight rows of buckets from 49152 points on — where the unmerged launch already takes the two-pass sort
             // (2 / 4 / 8 payloads: 0.78 -> 0.72, 0.93 -> 0.88, 1.22 -> 1.17 ms; four rows at 8 payloads: 1.26 — one round of lanes, the
             // longest chain sets the time; one payload, 2^15 points: 0.75 -> 0.89, the doubled rows leave the one-pass sort's range)
