@@ -34,7 +34,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("SQ counters per launch (averages over the launches of `bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1`: the piece-wise headline steps — three accumulation launches each, beside the next piece's sort — and the resident-scalars legs — one launch, alone)")
+print("SQ counters per launch (averages over the launches of `bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1`: the piece-wise headline steps — one accumulation launch per piece (four), beside the next piece's sort — and the resident-scalars legs — one launch, alone)")
 for k, v in sorted(agg.items()):
     if "accum29" in k or "reduce29" in k or "k_rx" in k or "k_digits" in k:
         wc = sum(v["SQ_WAVE_CYCLES"]) / len(v["SQ_WAVE_CYCLES"])
