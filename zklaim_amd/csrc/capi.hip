@@ -43,8 +43,11 @@ static constexpr size_t TIMER_MAX_PAIRS = 4096;              // a long-running h
 void KernelTimer::begin(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_timer_mu);
     pending = false;
-    if (!enabled || used >= TIMER_MAX_PAIRS) return;
-    if (used == pairs.size()) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; } pairs.push_back({a, b}); }
+    static const bool off = getenv("ZKG_KERNEL_TIMER") && atoi(getenv("ZKG_KERNEL_TIMER")) == 0;      // A/B switch: what the two event records per launch cost the step
+    if (off || !enabled || used >= TIMER_MAX_PAIRS) return;
+    // (timing only: no system-scope fence — the write-back of whatever the kernel before left dirty would be timed and would delay the kernel behind)
+    static const unsigned tf = hipEventDisableSystemFence;
+    if (used == pairs.size()) { hipEvent_t a, b; if (hipEventCreateWithFlags(&a, tf) != hipSuccess || hipEventCreateWithFlags(&b, tf) != hipSuccess) { enabled = false; return; } pairs.push_back({a, b}); }
     (void)hipEventRecord(pairs[used].first, s);
     pending = true;
 }

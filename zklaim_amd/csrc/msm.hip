@@ -1343,7 +1343,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     }
     if (done_ba) {}
     else if constexpr (sizeof(F) == sizeof(Fq)) {
-        static const int waves29 = getenv("ZKG_ACC29_WAVES") ? atoi(getenv("ZKG_ACC29_WAVES")) : 2;               // tuning aid
+        // wavefronts per SIMD: three (168 registers; the loop has no spill either way) when the launch has the chip to itself — a plain set sorted on
+        // the job's own stream: the resident call, 1.17 -> 1.14 ms alone — and two capped at ACC29_VGPRS where something is meant to run beside it: the
+        // next piece's sort of a piece-wise job, the witness multi-exponentiations of a proof (table launches)
+        static const int waves_env = getenv("ZKG_ACC29_WAVES") ? atoi(getenv("ZKG_ACC29_WAVES")) : 0;               // tuning aid: 2 or 3 everywhere
+        const int waves29 = waves_env ? waves_env : (job->sort_stream || gr.table || job->bucket_owner) ? 2 : 3;
         auto launch29 = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, rec29, stride29, g.B, job->sorted.as<uint32_t>(),
                                job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, (void *)buckets, gr.heavy_items.as<HeavyItem>(),
@@ -1761,6 +1765,7 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         // (confining this stream to 16 ... 128 compute units with a CU mask instead was measured: 2.11 -> 4.25 ... 2.70 ms — the sort needs the chip's width)
         bool ok = hipStreamCreateWithPriority(&g_sort_hi, hipStreamNonBlocking, hi) == hipSuccess;
+        // (these events without their system-scope fence — hipEventDisableSystemFence — were measured: 1.994 against 1.998 ms, nothing; an A/B on one box)
         for (MsmJob *w : {&J, &K}) ok = ok && hipEventCreateWithFlags(&w->ev_sorted, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_acc_done, hipEventDisableTiming) == hipSuccess;
         if (!ok) { g_sort_hi = nullptr; set_error("msm: sort stream"); return ZKG_ERROR; }
     }
