@@ -38,6 +38,11 @@ int DevBuf::reserve(size_t bytes) {
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 KernelTimer g_dominant_timer;
+bool crit_priority_for(int part, unsigned log_m) {
+    static const int parts = getenv("ZKG_CRIT_PRIO_PARTS") ? atoi(getenv("ZKG_CRIT_PRIO_PARTS")) : 7;
+    static const unsigned min_log = getenv("ZKG_CRIT_PRIO_MIN_LOG") ? (unsigned)atoi(getenv("ZKG_CRIT_PRIO_MIN_LOG")) : CRIT_PRIORITY_MIN_LOG;
+    return crit_priority_enabled() && (parts & part) && log_m >= min_log;
+}
 static std::mutex g_timer_mu;
 static constexpr size_t TIMER_MAX_PAIRS = 4096;              // a long-running host that never drains the timer stops recording here
 void KernelTimer::begin(hipStream_t s) {

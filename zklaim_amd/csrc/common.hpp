@@ -132,6 +132,7 @@ void msm_job_set_row_merge(MsmJob *j, uint32_t f);        // table launches with
 void msm_job_set_window(MsmJob *j, int c);                 // window bits for the next launches (0 = the size-based rule)
 void msm_job_set_critical(MsmJob *j, bool critical);   // the job is on its caller's critical path: its accumulate / fold / reduce wavefronts raise their issue priority (crit_wave_priority)
 static constexpr unsigned CRIT_PRIORITY_MIN_LOG = 20;     // ... from this domain size on (tools/r4_crit_prio_ab.sh, sparse-witness proofs, off -> on: 37 payloads / 2^20: 3.14 -> 3.07 ms; 20 payloads / 2^19 + 2^18: 2.13 -> 2.16; 8 payloads / 2^18: 1.12 -> 1.23)
+bool crit_priority_for(int part, unsigned log_m);        // part 1: matrix-vector + pointwise, 2: transforms, 4: the H job; tuning aids ZKG_CRIT_PRIO_PARTS (mask, default 7), ZKG_CRIT_PRIO_MIN_LOG
 bool crit_priority_enabled();                           // ZKG_CRIT_PRIO=0 switches the raised priorities of the critical-path kernels off (A/B)
 void msm_job_destroy(MsmJob *j);
 // d_gather (optional, n entries): scalar i is d_scalars[d_gather[i]] and stands for element d_gather[i] of every base set

@@ -409,7 +409,7 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
             B.xcd_tiles = (xcd_map && tiles % 8 == 0) ? (uint32_t)(tiles / 8) : 0;
             // the transforms are the prover's critical path at 2^20 (beside the witness multi-exponentiations); below, the G2 witness chain ends
             // as late as the H query and raised priorities here cost more there (CRIT_PRIORITY_MIN_LOG)
-            B.critical = (crit_priority_enabled() && n >= CRIT_PRIORITY_MIN_LOG) ? 1u : 0u;
+            B.critical = crit_priority_for(2, n) ? 1u : 0u;
             static const int radix_force = getenv("ZKG_NTT_RADIX2") ? (atoi(getenv("ZKG_NTT_RADIX2")) ? 2 : 4) : 0;          // A/B switch
             if (radix_force ? radix_force == 4 : large) {
                 const unsigned threads4 = (unsigned)std::min<size_t>(256, std::max<size_t>(64, rows * CW / 4));             // one thread per four rows of a column

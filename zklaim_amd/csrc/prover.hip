@@ -344,8 +344,9 @@ struct WitnessSrc {                           // dense: n x 4 limbs; or sparse: 
     const uint8_t *tags = nullptr; const uint32_t *idx = nullptr; const uint64_t *vals = nullptr; size_t count = 0;
 };
 // phase 1 of r1cs_to_qap_witness_map: z = [1 | w] resident and split, the three mat-vecs, the satisfiability flag
+static unsigned floor_log2(size_t x) { unsigned r = 0; while (x >>= 1) ++r; return r; }
 static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want_flag) {
-    const int crit = (crit_priority_enabled() && crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG)) ? 1 : 0;   // (see ntt_run_ex)
+    const int crit = crit_priority_for(1, floor_log2(crs->m)) ? 1 : 0;   // (see ntt_run_ex)
     hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
     Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -392,7 +393,7 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
 }
 // phase 2: the seven transforms and the pointwise step -> coefficients_for_H in aA
 static int compute_h_transforms(zkg_crs *crs, ProverSlot &S) {
-    const int crit = (crit_priority_enabled() && crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG)) ? 1 : 0;   // (see ntt_run_ex)
+    const int crit = crit_priority_for(1, floor_log2(crs->m)) ? 1 : 0;   // (see ntt_run_ex)
     hipStream_t s = S.stream;
     const size_t m = crs->m;
     Fr *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -455,7 +456,7 @@ static int slot_create(zkg_crs *crs, ProverSlot &S) {
              hip_ok(hipStreamCreateWithPriority(&S.stream_o, hipStreamNonBlocking, prio(2)), "hipStreamCreate", __FILE__, __LINE__);
         if (ok) {                                                            // a table launch runs at the table's window size
             msm_job_set_window(S.job_w1, crs->c_w); msm_job_set_window(S.job_w2, crs->c_w); msm_job_set_window(S.job_h, crs->H_query.c);
-            msm_job_set_critical(S.job_h, crs->m >= ((size_t)1 << CRIT_PRIORITY_MIN_LOG));                              // the H query's multi-exponentiation ends the proof; the witness jobs beside it have slack
+            msm_job_set_critical(S.job_h, crit_priority_for(4, floor_log2(crs->m)));                              // the H query's multi-exponentiation ends the proof; the witness jobs beside it have slack
             // H: sixteen windows in eight rows of buckets from 49152 points on — where the unmerged launch already takes the two-pass sort
             // (2 / 4 / 8 payloads: 0.78 -> 0.72, 0.93 -> 0.88, 1.22 -> 1.17 ms; four rows at 8 payloads: 1.26 — one round of lanes, the
             // longest chain sets the time; one payload, 2^15 points: 0.75 -> 0.89, the doubled rows leave the one-pass sort's range)
