@@ -369,3 +369,32 @@ def test_multi_device_exchange_over_rccl(zkg, oracle):
     got3 = _with_env("ZKG_MULTI_RCCL", 1, lambda: dup.msm(sc))
     dup.free()
     assert np.array_equal(got3, exp) and zkg.lib().zkg_multi_rccl_calls() == before + 2
+
+
+def test_sort_workgroup_forms_and_wave_counts_agree(zkg):
+    """The digit sort's two wide kernels exist as 1024- and 512-thread workgroups (the second runs beside an accumulation, msm.hip k_rx_scatter)
+    and the 29-bit accumulation as two capped or three wavefronts per SIMD; the library picks by context.  Forced each way in a process of its
+    own (the switches are read once), the resident multi-exponentiation returns the same point as this process's default path, for a size
+    that is and one that is not a multiple of four (16-byte and 4-byte digit loads), with a third of the scalars equal (an oversized bin)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import zklaim_amd as zkg
+from gpu_util import dev_bases_g1
+from util import random_fr_canonical
+zkg.init(0)
+for n in (70000, 65537 + 4096):
+    d_bases, bases, _ = dev_bases_g1(zkg, n, 0x51A0 + n)
+    sc = random_fr_canonical(n, 0x51A1 + n); sc[np.random.default_rng(n).integers(0, 3, n) == 0] = sc[0]
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    print(zkg.msm_g1_dev(d_bases.data_ptr(), d_sc.data_ptr(), n).tobytes().hex())
+'''
+    outs = []
+    for env in ({}, {"ZKG_SORT_WG": "512"}, {"ZKG_SORT_WG": "1024", "ZKG_ACC29_WAVES": "2"}, {"ZKG_ACC29_WAVES": "3", "ZKG_SORT_WG": "512"}):
+        r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-2:])
+    assert all(len(o) == 2 for o in outs)
+    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
