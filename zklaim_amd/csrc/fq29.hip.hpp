@@ -488,4 +488,5 @@ ZK_D void xyzz29_add_pair(Half29 &a, const Half29 &b, uint32_t r) {
     for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.c0.v[i]), "+v"(a.c1.v[i]));
 }
 
+
 }  // namespace zk

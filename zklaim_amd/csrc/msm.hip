@@ -1002,6 +1002,81 @@ __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(con
     }
 }
 
+// ---- 7''. the large reduction with its first phase on single lanes.  k_bucket_reduce29p walks a logical lane's 16 buckets as 31 pair
+//      additions in sequence — two thirds of its chain, at 126 ns of a SIMD per addition.  Here each of the workgroup's 256 THREADS takes 8
+//      buckets alone (xyzz29_add_lane: 85 ns of a SIMD per addition, 64 additions per wavefront-step): 15 steps of 5.6 us instead of 31 of
+//      4.7.  The 256 (sum, weighted sum) results go through LDS to the 128 pairs, two entries each, for the same scan and trees:
+//          sum_b b B_b (b local, 8 i + j)  =  8 sum_i i R_i + sum_i T_i,      sum_i i R_i = sum_{i >= 1} (suffix sum of R at i),
+//      a pair owning entries 2t, 2t + 1 adds four pair additions to the old chain (their sum for the scan, the odd entry's suffix, the
+//      pair's two suffixes, the pair's two weighted sums).  Same chunks and the same two results per chunk as the pair kernel.
+//      Bucket29 input only (the plain G1 path); the other shapes keep the pair / quad kernels.
+__global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29l(const Bucket29 *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
+                                                                             size_t in_set_stride, size_t out_set_stride, int critical) {
+    crit_wave_priority(critical);
+    constexpr int RED_LANES = RedGeom<Fq>::LANES, NT = 2 * RED_LANES, PER = 8, RED_CHUNK = NT * PER;      // = RED_LANES << RED_L_LOG_LARGE
+    static_assert(RED_CHUNK == (RED_LANES << RED_L_LOG_LARGE), "the lane-form reduction keeps the large reduction's chunks");
+    extern __shared__ unsigned char red_smem[];
+    LdsPoint29 *sh = reinterpret_cast<LdsPoint29 *>(red_smem);             // 2 * NT points
+    const uint32_t i = threadIdx.x;
+    const uint32_t w = blockIdx.x / chunks_per_window, ch = blockIdx.x % chunks_per_window;
+    const Bucket29 *X = buckets + blockIdx.y * in_set_stride + (size_t)w * B;
+    out += blockIdx.y * out_set_stride;
+    {   // phase 1: this thread's 8 buckets — run = their sum, T0 = sum_j j B_(base + j)
+        const uint32_t base = ch * RED_CHUNK + i * PER;
+        XYZZ29q run = XYZZ29q::inf(), T0 = XYZZ29q::inf();
+        XYZZ29q cur = load_bucket29<true>(X, base + PER - 1, B, 0);
+        for (int j = PER - 1; j >= 1; --j) {
+            const XYZZ29q nxt = load_bucket29<true>(X, base + j - 1, B, 0);  // the next bucket arrives under the two additions
+            xyzz29_add_lane(run, cur);
+            xyzz29_add_lane(T0, run);
+            cur = nxt;
+        }
+        xyzz29_add_lane(run, cur);
+        sh[i].p = run; sh[NT + i].p = T0;
+    }
+    __syncthreads();
+    // phase 2: pairs.  Pair t owns entries 2t and 2t + 1.
+    const uint32_t t = i >> 1, r = i & 1;
+    const Half29 R1 = lds_load_half29(sh + 2 * t + 1, r);
+    Half29 Q = lds_load_half29(sh + 2 * t, r);
+    xyzz29_add_pair(Q, R1, r);                                           // the pair's sum
+    Half29 Tp = lds_load_half29(sh + NT + 2 * t, r);
+    xyzz29_add_pair(Tp, lds_load_half29(sh + NT + 2 * t + 1, r), r);     // the pair's weighted sums
+    __syncthreads();                                                     // (every entry has been read: the scan reuses the first RED_LANES slots)
+    for (uint32_t d = 1; d < RED_LANES; d <<= 1) {                       // inclusive suffix scan of the pair sums
+        lds_store_half29(sh + t, Q, r);
+        __syncthreads();
+        if (t + d < RED_LANES) xyzz29_add_pair(Q, lds_load_half29(sh + t + d, r), r);
+        __syncthreads();
+    }
+    const Half29 P = Q;                                                  // pair 0: total of the chunk
+    lds_store_half29(sh + t, Q, r);
+    __syncthreads();
+    Half29 V = t + 1 < RED_LANES ? lds_load_half29(sh + t + 1, r) : Half29::inf();     // the sum of everything above this pair
+    xyzz29_add_pair(V, R1, r);                                           // suffix at entry 2t + 1
+    if (t >= 1) xyzz29_add_pair(V, Q, r);                                // + suffix at entry 2t (entry 0 weighs nothing)
+    __syncthreads();
+    lds_store_half29(sh + t, V, r); lds_store_half29(sh + RED_LANES + t, Tp, r);
+    __syncthreads();
+    for (uint32_t d = RED_LANES / 2; d >= 1; d >>= 1) {                  // two trees side by side, as in the pair kernel
+        if (t < d) { Half29 a = lds_load_half29(sh + t, r); xyzz29_add_pair(a, lds_load_half29(sh + t + d, r), r); lds_store_half29(sh + t, a, r); }
+        else if (t >= RED_LANES / 2 && t < RED_LANES / 2 + d) {
+            const uint32_t u = RED_LANES + (t - RED_LANES / 2);
+            Half29 a = lds_load_half29(sh + u, r); xyzz29_add_pair(a, lds_load_half29(sh + u + d, r), r); lds_store_half29(sh + u, a, r);
+        }
+        __syncthreads();
+    }
+    if (t == 0) lds_store_half29(sh + 1, P, r);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        XYZZ<Fq> E = store_point29(sh[0].p);
+        for (int k = 0; k < 3; ++k) E = E.dbl();                         // * 8 buckets per thread
+        E.add(store_point29(sh[RED_LANES].p));
+        out[2 * (size_t)blockIdx.x] = store_point29(sh[1].p); out[2 * (size_t)blockIdx.x + 1] = E.normalized();
+    }
+}
+
+
 // ---- 7b'. the fold of a table launch's bucket rows on the 29-bit records: a pair of lanes per bucket adds its W rows in sequence (xyzz29_add_pair; rows
 //      without entries were never written and are skipped by their length), Bucket29 in, Bucket29 out — the accumulation stores its accumulators as they
 //      are and the reduction loads the folded set as it is: no conversion anywhere between the gathers and the chunk results.
@@ -1401,7 +1476,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
             auto launch_redp = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), lds, s, rin, g.B, gr.cpw, rout, in_stride, L.red_out, job->critical ? 1 : 0); };
             // one bucket per logical lane (a table launch's folded set: the prover): the chain is 17 steps either way and the quad kernel's two
             // wavefronts per SIMD hide its LDS rounds a little better (90 against 94 us); the pair form is for the long chains
-            if (!red_quad && red_l_log != RED_L_LOG_TINY) {
+            static const bool red_pair = getenv("ZKG_REDUCE_PAIR") != nullptr;                            // A/B switch: the pair kernel for the large reduction too
+            if (!red_quad && !red_pair && out29 && red_l_log == RED_L_LOG_LARGE) {
+                hipLaunchKernelGGL(k_bucket_reduce29l, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), 4 * RG::LANES * sizeof(LdsPoint29), s,
+                                   reinterpret_cast<const Bucket29 *>(rin), g.B, gr.cpw, rout, in_stride, L.red_out, job->critical ? 1 : 0);
+            } else if (!red_quad && red_l_log != RED_L_LOG_TINY) {
                 if (out29) {
                     if (red_l_log == RED_L_LOG_LARGE) launch_redp(k_bucket_reduce29p<RED_L_LOG_LARGE, true>);
                     else if (red_l_log == RED_L_LOG_SMALL) launch_redp(k_bucket_reduce29p<RED_L_LOG_SMALL, true>);
@@ -1988,6 +2067,7 @@ int msm_configure() {
     ok = ok && hipFuncSetAttribute((const void *)k_sum_partials<Fq2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (int)sizeof(LdsPoint<Fq2>)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MAX_C - 1)) * 4) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)k_bucket_reduce29l, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RedGeom<Fq>::LANES * (int)sizeof(LdsPoint29)) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_SLICE + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_rx_scatter<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (512 * RX_PER_THREAD + 4 * RX_MAX_CB + 8) * 4) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void *)k_rx_fine<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (RX_FINE_MAX + 3 * 1024) * 4) == hipSuccess;
