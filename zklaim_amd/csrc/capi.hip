@@ -83,6 +83,17 @@ struct Pool {
     std::mutex mu; std::condition_variable cv_work, cv_done;
     std::shared_ptr<Run> cur; uint64_t epoch = 0; bool stop = false;
     std::mutex run_mu;                         // one parallel_for at a time
+    // prewake: a caller that is about to wait for the GPU and will hand out work right after (msm_job_finish) wakes the workers ahead of it; they
+    // poll the epoch for at most `spin_us` and go back to sleep.  Waking fifteen sleeping threads through one condition variable costs the
+    // work they were woken for 20 - 35 us (tools/pool_wake_bench.hip), a third of the host tail of a multi-exponentiation.
+    std::atomic<uint64_t> epoch_a{0}, hint{0}; std::atomic<int64_t> spin_deadline_ns{0};
+    static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void prewake(unsigned spin_us) {
+        if (workers.empty()) return;
+        spin_deadline_ns.store(now_ns() + (int64_t)spin_us * 1000);
+        { std::lock_guard<std::mutex> lk(mu); hint.fetch_add(1); }
+        cv_work.notify_all();
+    }
     Pool() {
         unsigned hw = std::thread::hardware_concurrency();
         int nw = (int)(hw > 16 ? 15 : (hw > 1 ? hw - 1 : 0));
@@ -100,14 +111,23 @@ struct Pool {
         }
     }
     void loop() {
-        uint64_t seen = 0;
+        uint64_t seen = 0, seen_hint = 0;
         for (;;) {
             std::shared_ptr<Run> r;
+            bool spin = false;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || epoch != seen; });
+                cv_work.wait(lk, [&] { return stop || epoch != seen || hint.load() != seen_hint; });
                 if (stop) return;
-                seen = epoch; r = cur;
+                if (epoch != seen) { seen = epoch; r = cur; }
+                else { seen_hint = hint.load(); spin = true; }
+            }
+            if (spin) {                                                       // woken ahead of the work: poll for it, bounded
+                while (epoch_a.load(std::memory_order_acquire) == seen && now_ns() < spin_deadline_ns.load()) __builtin_ia32_pause();
+                std::lock_guard<std::mutex> lk(mu);
+                seen_hint = hint.load();
+                if (stop) return;
+                if (epoch != seen) { seen = epoch; r = cur; }
             }
             if (r) drain(*r);
         }
@@ -120,7 +140,7 @@ struct Pool {
         if (wait_for_pool) rl.lock();
         else if (!rl.try_lock()) { for (int i = 0; i < count; ++i) f(i); return; }
         auto r = std::make_shared<Run>(); r->fn = f; r->n = count;
-        { std::lock_guard<std::mutex> lk(mu); cur = r; ++epoch; }
+        { std::lock_guard<std::mutex> lk(mu); cur = r; ++epoch; epoch_a.store(epoch, std::memory_order_release); }
         cv_work.notify_all();
         drain(*r);
         std::unique_lock<std::mutex> lk(mu);
@@ -130,6 +150,12 @@ struct Pool {
 }  // namespace
 static Pool &host_pool() { static Pool pool; return pool; }
 void host_parallel_for(int n, const std::function<void(int)> &fn) { host_pool().run(n, fn, false); }
+// Off unless ZKG_POOL_PREWAKE=1.  Measured (tools/r4_prewake_ab.sh, tools/pool_wake_bench.hip): the pool's sixteen 18-us tasks take 39 us instead of 51 when
+// the workers were woken 250 us ahead, the host tail of a 2^20-point job 64 - 74 us instead of 71 - 94, a sparse proof at 8 / 37 payloads 1.13 / 3.08 ms instead
+// of 1.15 - 1.19 / 3.09 - 3.12 — and the 2^20-point step itself does not move (1.868 against 1.878 ms).  Fifteen threads polling for a quarter of a
+// millisecond per multi-exponentiation is not worth that by default on a host shared by eight ranks.
+bool host_pool_prewake_enabled() { static const bool on = getenv("ZKG_POOL_PREWAKE") && atoi(getenv("ZKG_POOL_PREWAKE")) != 0; return on; }
+void host_pool_prewake(unsigned spin_us) { if (host_pool_prewake_enabled()) host_pool().prewake(spin_us); }
 void host_parallel_for_wait(int n, const std::function<void(int)> &fn) { host_pool().run(n, fn, true); }
 
 // ---- ABI point encodings -----------------------------------------------------------------------

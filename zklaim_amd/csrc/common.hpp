@@ -47,6 +47,8 @@ extern KernelTimer g_dominant_timer;
 // host_parallel_for: a caller that finds the pool busy runs its tasks inline (short loops on a proof's latency path);
 // host_parallel_for_wait: queues behind the running loop (bulk work that must be parallel: hashing a 200 MB key blob)
 void host_parallel_for(int n, const std::function<void(int)> &fn);
+bool host_pool_prewake_enabled();                 // ZKG_POOL_PREWAKE=1
+void host_pool_prewake(unsigned spin_us);      // the caller will call host_parallel_for within spin_us: wake the workers now, let them poll for it
 void host_parallel_for_wait(int n, const std::function<void(int)> &fn);
 
 // ---------------- NTT (ntt.hip) ----------------

@@ -1295,6 +1295,7 @@ struct MsmJob {
     // piece-wise jobs (msm_g1_host_scalars): `resume` — this launch's accumulation continues the buckets of the launch before it;
     // `defer_reduce` — more pieces follow: no reduction, nothing copied back; `c_fixed` — every piece uses the whole job's window size
     bool resume = false, defer_reduce = false; bool last_out29 = false;
+    hipEvent_t ev_tail = nullptr; bool tail_recorded = false;      // recorded behind the job's last accumulation (see msm_job_finish)
     bool critical = false;                        // msm_job_set_critical: the accumulate / fold / reduce kernels raise their wavefronts' issue priority
     // a second job that alternates with this one over the pieces of one multi-exponentiation accumulates into THIS job's buckets
     MsmJob *bucket_owner = nullptr;
@@ -1441,6 +1442,10 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
                            views, job->sorted.as<uint32_t>(), job->offsets.as<uint32_t>(), job->order.as<uint32_t>(), lanes, buckets,
                            gr.heavy_items.as<HeavyItem>(), gr.heavy_buckets.as<HeavyBucket>(), gr.heavy_counters.as<uint32_t>(), L);
     if (time_it) g_dominant_timer.end(s);
+    if (!job->defer_reduce && host_pool_prewake_enabled()) {                    // (opt-in) msm_job_finish wakes the host pool when the stream gets here: what follows is 0.1 - 0.3 ms
+        if (!job->ev_tail && hipEventCreateWithFlags(&job->ev_tail, hipEventDisableTiming) != hipSuccess) job->ev_tail = nullptr;
+        job->tail_recorded = job->ev_tail && hipEventRecord(job->ev_tail, s) == hipSuccess;
+    }
     hipLaunchKernelGGL(k_heavy_parts<F>, dim3(HEAVY_PART_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
                        views, job->sorted.as<uint32_t>(), gr.heavy_items.as<HeavyItem>(), gr.heavy_counters.as<uint32_t>(), gr.heavy_partials.as<XYZZ<F>>(), buckets, L, (int)out29);
     hipLaunchKernelGGL(k_heavy_merge<F>, dim3(HEAVY_MERGE_BLOCKS, ns), dim3(256), 256 * sizeof(LdsPoint<F>), s,
@@ -1674,6 +1679,7 @@ void msm_job_destroy(MsmJob *j) {
     for (auto &gr : j->group) gr.release();
     if (j->aux) { (void)hipStreamSynchronize(j->aux); (void)hipStreamDestroy(j->aux); }
     if (j->ev_fork) (void)hipEventDestroy(j->ev_fork);
+    if (j->ev_tail) (void)hipEventDestroy(j->ev_tail);
     if (j->ev_join) (void)hipEventDestroy(j->ev_join);
     if (j->own_stream) (void)hipStreamDestroy(j->stream);
     delete j;
@@ -1743,6 +1749,11 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
 int msm_job_finish(MsmJob *job, G1 *out_g1, G2 *out_g2) {
     static const bool dbg = getenv("ZKG_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
+    // The host's tail (host_combine) hands sixteen windows' chunk sums to the host pool the moment the stream has drained; its workers have been
+    // asleep for the whole call, and waking them through their condition variable costs that work ~12 us.  With ZKG_POOL_PREWAKE=1: wait for the last
+    // accumulation first, wake the pool then — it polls for the work while the fold / reduction run (0.1 - 0.3 ms) — and only then wait for the
+    // stream.  Off by default: see host_pool_prewake.
+    if (job->tail_recorded) { job->tail_recorded = false; if (hipEventSynchronize(job->ev_tail) == hipSuccess) host_pool_prewake(600); }
     ZK_HIP(hipStreamSynchronize(job->stream));
     const auto t1 = std::chrono::steady_clock::now();
     struct Lap { bool on; std::chrono::steady_clock::time_point a, b; ~Lap() { if (on) fprintf(stderr, "[zkg]     job finish: waited %.3f ms, host combine %.3f ms\n", std::chrono::duration<float, std::milli>(b - a).count(), std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - b).count()); } } lap_{dbg, t0, t1};
@@ -2089,6 +2100,7 @@ void msm_release_all() {
         for (auto &gr : k.group) gr.release();
         if (k.aux) { (void)hipStreamSynchronize(k.aux); (void)hipStreamDestroy(k.aux); k.aux = nullptr; }
         if (k.ev_fork) { (void)hipEventDestroy(k.ev_fork); k.ev_fork = nullptr; }
+        if (k.ev_tail) { (void)hipEventDestroy(k.ev_tail); k.ev_tail = nullptr; k.tail_recorded = false; }
         if (k.ev_join) { (void)hipEventDestroy(k.ev_join); k.ev_join = nullptr; }
         for (MsmJob *w : {&j, &k}) {
             if (w->ev_sorted) { (void)hipEventDestroy(w->ev_sorted); w->ev_sorted = nullptr; }
@@ -2099,6 +2111,7 @@ void msm_release_all() {
     if (j.copy) { (void)hipStreamSynchronize(j.copy); (void)hipStreamDestroy(j.copy); j.copy = nullptr; }
     for (auto &e : j.ev_piece) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (j.ev_fork) { (void)hipEventDestroy(j.ev_fork); j.ev_fork = nullptr; }
+    if (j.ev_tail) { (void)hipEventDestroy(j.ev_tail); j.ev_tail = nullptr; j.tail_recorded = false; }
     if (j.ev_join) { (void)hipEventDestroy(j.ev_join); j.ev_join = nullptr; }
 }
 
