@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29p(con
 //      4.7.  The 256 (sum, weighted sum) results go through LDS to the 128 pairs, two entries each, for the same scan and trees:
 //          sum_b b B_b (b local, 8 i + j)  =  8 sum_i i R_i + sum_i T_i,      sum_i i R_i = sum_{i >= 1} (suffix sum of R at i),
 //      a pair owning entries 2t, 2t + 1 adds four pair additions to the old chain (their sum for the scan, the odd entry's suffix, the
-//      pair's two suffixes, the pair's two weighted sums).  Same chunks and the same two results per chunk as the pair kernel.
+//      pair's two suffixes, the pair's two weighted sums).  Same chunks as the pair kernel; three results per chunk (see the end).
 //      Bucket29 input only (the plain G1 path); the other shapes keep the pair / quad kernels.
 __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29l(const Bucket29 *buckets, uint32_t B, uint32_t chunks_per_window, XYZZ<Fq> *out,
                                                                              size_t in_set_stride, size_t out_set_stride, int critical) {
@@ -1068,12 +1068,9 @@ __global__ __launch_bounds__(2 * RedGeom<Fq>::LANES) void k_bucket_reduce29l(con
     }
     if (t == 0) lds_store_half29(sh + 1, P, r);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        XYZZ<Fq> E = store_point29(sh[0].p);
-        for (int k = 0; k < 3; ++k) E = E.dbl();                         // * 8 buckets per thread
-        E.add(store_point29(sh[RED_LANES].p));
-        out[2 * (size_t)blockIdx.x] = store_point29(sh[1].p); out[2 * (size_t)blockIdx.x + 1] = E.normalized();
-    }
+    // three results per chunk: the sum, sum_i T_i, sum_i i R_i.  The host adds the windows' chunks up anyway and multiplies the third by 8 (buckets
+    // per thread) once per window: three doublings and an addition on ONE lane's 32-bit path here were 25 us at the end of every workgroup's chain.
+    if (threadIdx.x < 3) out[3 * (size_t)blockIdx.x + threadIdx.x] = store_point29(threadIdx.x == 0 ? sh[1].p : threadIdx.x == 1 ? sh[RED_LANES].p : sh[0].p);
 }
 
 
@@ -1263,6 +1260,7 @@ struct MsmGroup {                   // the base sets of one field in a launch: a
     DevBuf ba_start, ba_pre, ba_planes;                // batched-affine levels (msm_ba.inc): bucket-start bits, prefix-product scratch, the levels' coordinate planes
     void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false; int nsets = 0;
     int out_index[MSM_MAX_SETS] = {0};                 // position of each set among the launch's sets of this field
+    int red_slots = 2; size_t red_stride = 0;                                // results per chunk (k_bucket_reduce29l: 3, see there), elements per set in red_out
     uint32_t cpw = 0, red_windows = 0; size_t nred = 0; int chunk_log = 0;   // reduce geometry per set: chunks per window, windows reduced, chunk results, log2(buckets per chunk)
     int host_reserve(size_t bytes) {
         if (bytes <= host_cap) return 0;
@@ -1327,10 +1325,11 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     gr.chunk_log = RG::LANES_LOG + red_l_log;
     gr.cpw = (g.B + (1u << gr.chunk_log) - 1) >> gr.chunk_log; gr.nred = (size_t)gr.red_windows * gr.cpw;
     DevBuf &bucket_buf = job->bucket_owner ? job->bucket_owner->group[sizeof(F) != sizeof(Fq) ? 1 : 0].buckets : gr.buckets;
-    SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 2;
+    gr.red_slots = 2;
+    SetLayout L; L.buckets = total_buckets; L.items = max_items; L.heavy = max_heavy; L.partials = max_items; L.folded = g.B; L.red_out = gr.nred * 3;      // two results per chunk, three from k_bucket_reduce29l (gr.red_slots)
     if (gr.heavy_items.reserve(ns * max_items * sizeof(HeavyItem)) || gr.heavy_buckets.reserve(ns * max_heavy * sizeof(HeavyBucket)) ||
         gr.heavy_counters.reserve(8 * MSM_MAX_SETS) || gr.heavy_partials.reserve(ns * max_items * sizeof(XYZZ<F>)) ||
-        bucket_buf.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) ||
+        bucket_buf.reserve(ns * total_buckets * std::max(sizeof(XYZZ<F>), sizeof(Bucket29))) || gr.red_out.reserve(ns * L.red_out * sizeof(XYZZ<F>)) || ((gr.red_stride = L.red_out), false) ||
         (gr.table && gr.folded.reserve(ns * (size_t)g.B * std::max(sizeof(XYZZ<F>), sizeof(Bucket29)))) || gr.host_reserve(ns * L.red_out * sizeof(XYZZ<F>))) return ZKG_ERROR;
     // (gr.heavy_counters: cleared by the job's k_digits)
     XYZZ<F> *buckets = bucket_buf.as<XYZZ<F>>();
@@ -1483,6 +1482,7 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
             // wavefronts per SIMD hide its LDS rounds a little better (90 against 94 us); the pair form is for the long chains
             static const bool red_pair = getenv("ZKG_REDUCE_PAIR") != nullptr;                            // A/B switch: the pair kernel for the large reduction too
             if (!red_quad && !red_pair && out29 && red_l_log == RED_L_LOG_LARGE) {
+                gr.red_slots = 3;
                 hipLaunchKernelGGL(k_bucket_reduce29l, dim3((unsigned)gr.nred, ns), dim3(2 * RG::LANES), 4 * RG::LANES * sizeof(LdsPoint29), s,
                                    reinterpret_cast<const Bucket29 *>(rin), g.B, gr.cpw, rout, in_stride, L.red_out, job->critical ? 1 : 0);
             } else if (!red_quad && red_l_log != RED_L_LOG_TINY) {
@@ -1526,16 +1526,19 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
 template <class F>
 static XYZZ<F> host_combine(const MsmJob *job, const MsmGroup &gr, int set) {
     const MsmGeom g = job->g; const uint32_t cpw = gr.cpw, W = gr.red_windows;
-    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(gr.host_red) + (size_t)set * gr.nred * 2;
+    const XYZZ<F> *red = reinterpret_cast<const XYZZ<F> *>(gr.host_red) + (size_t)set * gr.red_stride;
+    const size_t sl = (size_t)gr.red_slots;                                     // 2: (P, U) per chunk; 3: (P, T, A) with U = T + 8 A (k_bucket_reduce29l)
     std::vector<XYZZ<F>> V(W);
     auto window = [&](int w) {
-        XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf();
+        XYZZ<F> Usum = XYZZ<F>::inf(), suffix = XYZZ<F>::inf(), weighted = XYZZ<F>::inf(), Asum = XYZZ<F>::inf();
         for (int ch = (int)cpw - 1; ch >= 0; --ch) {
-            const XYZZ<F> &P = red[2 * ((size_t)w * cpw + ch)], &U = red[2 * ((size_t)w * cpw + ch) + 1];
+            const XYZZ<F> &P = red[sl * ((size_t)w * cpw + ch)], &U = red[sl * ((size_t)w * cpw + ch) + 1];
             Usum.add(U);
+            if (sl == 3) Asum.add(red[sl * ((size_t)w * cpw + ch) + 2]);
             if (ch >= 1) { suffix.add(P); weighted.add(suffix); }           // sum_ch ch * P_ch
             else suffix.add(P);                                             // suffix == P_w now
         }
+        if (sl == 3 && !Asum.is_inf()) { for (int i = 0; i < 3; ++i) Asum = Asum.dbl(); Usum.add(Asum); }
         if (!weighted.is_inf()) for (int i = 0; i < gr.chunk_log; ++i) weighted = weighted.dbl();         // * buckets per chunk
         Usum.add(weighted); Usum.add(suffix);
         V[w] = Usum;
