@@ -502,3 +502,70 @@ def test_h_sharding_rejects_bad_arguments(zkg):
     rc, proof = crs.prove(w, r, s)
     assert rc == 0 and proof.hex() == case["proof_hex"]
     crs.free()
+
+
+def test_unsatisfied_only_in_a_long_row_is_refused(zkg):
+    """The satisfiability gate (snark.cpp:121-124) is evaluated in two places on the GPU: k_r1cs_eval tests a row whose three sides it holds in
+    registers, k_r1cs_check_rows the rows with a long side (packing / addition rows, filled in by k_r1cs_long).  A witness bit is flipped that
+    keeps every short row it touches satisfied (its booleanity constraint) and breaks a long one — found here with Python integers over the
+    CSR matrices — and the prover must refuse it; the untouched witness still proves."""
+    keep = []
+    pl = dict(attrs=[1994, 7, 42, 0, 5], refs=[2000, 7, 41, 0, 0], ops=["less", "eq", "greater", "noop", "noop"], salt=0x10A6)
+    ck = zkg.ZklaimCircuit(zkg.make_ctx([pl], keep))
+    assert ck.is_satisfied()
+    w = ck.witness()
+    mats = ck.csr()
+    rinv = pow(1 << 256, -1, R)
+    to_int = lambda a: (sum(int(a[i]) << (64 * i) for i in range(4)) * rinv) % R
+    one = arr([1], R)[0]
+    z = [1] + [to_int(x) for x in w]
+    LONG_ROW = 24                                                            # prover.hip
+    ncons = ck.r1cs.num_constraints
+    is_long = np.zeros(ncons, bool)
+    for rp, _, _ in mats:
+        is_long |= np.diff(rp.astype(np.int64)) > LONG_ROW
+    rows_of = {}
+    for rp, col, _ in mats:
+        row_index = np.repeat(np.arange(ncons), np.diff(rp.astype(np.int64)))
+        for r_, c_ in zip(row_index[is_long[row_index]], col[is_long[row_index]]):
+            rows_of.setdefault(int(c_), set()).add(int(r_))                   # variables that occur in a long row
+    all_rows_of = {}
+    for rp, col, _ in mats:
+        row_index = np.repeat(np.arange(ncons), np.diff(rp.astype(np.int64)))
+        sel = np.isin(col, np.fromiter(rows_of.keys(), dtype=np.int64))
+        for r_, c_ in zip(row_index[sel], col[sel]):
+            all_rows_of.setdefault(int(c_), set()).add(int(r_))
+
+    def side(m, row, zz):
+        rp, col, val = mats[m]
+        return sum(to_int(val[k]) * zz[int(col[k])] for k in range(int(rp[row]), int(rp[row + 1]))) % R
+
+    chosen = None
+    for c_ in sorted(rows_of):
+        if c_ == 0 or z[c_] not in (0, 1):
+            continue
+        zz = list(z); zz[c_] = 1 - z[c_]
+        ok_short, broke_long = True, False
+        for row in all_rows_of[c_]:
+            sat = side(0, row, zz) * side(1, row, zz) % R == side(2, row, zz)
+            if is_long[row]:
+                broke_long |= not sat
+            elif not sat:
+                ok_short = False
+        if ok_short and broke_long:
+            chosen = c_
+            break
+    assert chosen is not None, "no bit whose flip breaks long rows only"
+    kp = zkg.Keypair(ck.r1cs, random_fr_canonical(5, 0x10A7))
+    crs = zkg.Crs(kp.pk)
+    rs = random_fr_canonical(2, 0x10A8)
+    rc, proof = crs.prove(w, rs[0], rs[1])
+    assert rc == 0
+    wbad = w.copy(); wbad[chosen - 1] = 0 if z[chosen] == 1 else one
+    assert crs.prove(wbad, rs[0], rs[1])[0] == zkg.UNSATISFIED
+    tags, idx, vals = ck.sparse_witness()
+    tbad = tags.copy(); tbad[chosen - 1] = 0 if z[chosen] == 1 else 1
+    assert crs.prove_sparse(tbad, idx, vals, rs[0], rs[1])[0] == zkg.UNSATISFIED
+    rc2, again = crs.prove(w, rs[0], rs[1])
+    assert rc2 == 0 and again == proof
+    crs.free(); kp.free()

@@ -171,25 +171,33 @@ namespace zk {
 // Rows C..C+l of aA carry the input-consistency terms (r1cs_to_qap_witness_map).
 static constexpr uint32_t LONG_ROW = 24;
 
-ZK_D Fr row_dot_short(const uint32_t *rp, const uint32_t *col, const Fr *val, const Fr *z, size_t i) {
+ZK_D Fr row_dot_short(const uint32_t *rp, const uint32_t *col, const Fr *val, const Fr *z, size_t i, bool &is_long) {
     Fr acc = Fr::zero();
     uint32_t k = rp[i], e = rp[i + 1];
-    if (e - k > LONG_ROW) return acc;                      // filled in by k_r1cs_long
+    if (e - k > LONG_ROW) { is_long = true; return acc; }  // filled in by k_r1cs_long
     for (; k < e; ++k) acc += val[k] * z[col[k]];
     return acc;
 }
+// Device-scope atomics only (no fence: a release fence writes back the XCD's whole L2, and one per workgroup behind the mat-vec's 96 MB of
+// fresh output doubled that stage at 2^20): the OR returns its old value and the lane waits for it, so it has been performed before the
+// workgroup's barrier and ticket.
+ZK_D void or_and_wait(uint32_t *word) { const uint32_t old = atomicOr(word, 1u); asm volatile("" : : "v"(old) : "memory"); }
 __global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
                                                     const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
                                                     const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
-                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, int critical) {
+                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, int critical, uint32_t *flag /* or null */) {
     crit_wave_priority(critical);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
     if (i < C) {
-        a = row_dot_short(a_rp, a_col, a_val, z, i);
-        b = row_dot_short(b_rp, b_col, b_val, z, i);
-        c = row_dot_short(c_rp, c_col, c_val, z, i);
+        bool is_long = false;
+        a = row_dot_short(a_rp, a_col, a_val, z, i, is_long);
+        b = row_dot_short(b_rp, b_col, b_val, z, i, is_long);
+        c = row_dot_short(c_rp, c_col, c_val, z, i, is_long);
+        // the satisfiability gate (snark.cpp:121-124) for this row, here where its three values are in registers: a kernel of its own over
+        // the stored vectors stood 14 us (8 payloads) ... 53 us (37) in front of the transforms.  Rows with a long side: k_r1cs_check_rows.
+        if (flag && !is_long && a * b != c) or_and_wait(flag);
     } else if (i <= (size_t)C + l) {
         a = z[i - C];
     }
@@ -215,15 +223,19 @@ __global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_
     }
     if (lane == 0) (mtx == 0 ? aA : mtx == 1 ? aB : aC)[row] = acc.normalized();
 }
-// Device-scope atomics only (no fence: a release fence writes back the XCD's whole L2, and one per workgroup behind the mat-vec's 96 MB of
-// fresh output doubled that stage at 2^20): the OR returns its old value and the lane waits for it, so it has been performed before the
-// workgroup's barrier and ticket.
-ZK_D void or_and_wait(uint32_t *word) { const uint32_t old = atomicOr(word, 1u); asm volatile("" : : "v"(old) : "memory"); }
 // flag[0] |= 1 when a row violates <A,z><B,z> = <C,z>: the pb.is_satisfied() gate of snark.cpp:121-124.  The last workgroup to finish
 // (ticket in flag[1]) writes the verdict straight into the caller's pinned word: no copy launch between the mat-vec and the transforms.
 __global__ __launch_bounds__(256) void k_r1cs_check(const Fr *aA, const Fr *aB, const Fr *aC, uint32_t C, uint32_t *flag, uint32_t *host_flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C && aA[i] * aB[i] != aC[i]) or_and_wait(flag);
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(flag + 1, 1u) == gridDim.x - 1) host_flag[0] = atomicOr(flag, 0u);
+}
+// the same gate over the rows k_r1cs_long filled in (entries of its list; a row listed twice is checked twice), behind it in stream order —
+// k_r1cs_eval has tested every other row — and the verdict to the caller's pinned word
+__global__ __launch_bounds__(256) void k_r1cs_check_rows(const uint32_t *list, uint32_t n_long, const Fr *aA, const Fr *aB, const Fr *aC, uint32_t *flag, uint32_t *host_flag) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_long) { const uint32_t row = list[j] & 0x3fffffffu; if (aA[row] * aB[row] != aC[row]) or_and_wait(flag); }
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(flag + 1, 1u) == gridDim.x - 1) host_flag[0] = atomicOr(flag, 0u);
 }
@@ -347,6 +359,7 @@ struct WitnessSrc {                           // dense: n x 4 limbs; or sparse: 
 static unsigned floor_log2(size_t x) { unsigned r = 0; while (x >>= 1) ++r; return r; }
 static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bool want_flag) {
     const int crit = crit_priority_for(1, floor_log2(crs->m)) ? 1 : 0;   // (see ntt_run_ex)
+    static const bool fused_check = getenv("ZKG_CHECK_KERNEL") == nullptr;                                // A/B switch: the satisfiability check as a kernel of its own over the stored vectors
     hipStream_t s = S.stream; uint32_t *flag_out = S.flag_host;
     const size_t m = crs->m;
     Fr *z = S.z.as<Fr>(), *aA = S.aABC.as<Fr>(), *aB = aA + m, *aC = aA + 2 * m;
@@ -377,14 +390,15 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                        crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(),
-                       z, crs->C, crs->l, m, aA, aB, aC, crit);
+                       z, crs->C, crs->l, m, aA, aB, aC, crit, (want_flag && fused_check) ? words : nullptr);
     if (crs->n_long)
         hipLaunchKernelGGL(k_r1cs_long, dim3((crs->n_long + 3) / 4), dim3(256), 0, s, crs->long_rows.as<uint32_t>(), crs->n_long,
                            crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                            crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                            crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(), z, aA, aB, aC);
     if (want_flag) {
-        if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, words, flag_out);
+        if (crs->C && fused_check) hipLaunchKernelGGL(k_r1cs_check_rows, dim3(std::max<uint32_t>(1, (crs->n_long + 255) / 256)), dim3(256), 0, s, crs->long_rows.as<uint32_t>(), crs->n_long, aA, aB, aC, words, flag_out);
+        else if (crs->C) hipLaunchKernelGGL(k_r1cs_check, dim3((crs->C + 255) / 256), dim3(256), 0, s, aA, aB, aC, crs->C, words, flag_out);
         if (S.ev_ok) (void)hipEventRecord(S.ev[3], s);
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[1], s);
