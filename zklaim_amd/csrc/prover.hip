@@ -182,36 +182,10 @@ ZK_D Fr row_dot_short(const uint32_t *rp, const uint32_t *col, const Fr *val, co
 // fresh output doubled that stage at 2^20): the OR returns its old value and the lane waits for it, so it has been performed before the
 // workgroup's barrier and ticket.
 ZK_D void or_and_wait(uint32_t *word) { const uint32_t old = atomicOr(word, 1u); asm volatile("" : : "v"(old) : "memory"); }
-__global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
-                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
-                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
-                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, int critical, uint32_t *flag /* or null */) {
-    crit_wave_priority(critical);
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
-    if (i < C) {
-        bool is_long = false;
-        a = row_dot_short(a_rp, a_col, a_val, z, i, is_long);
-        b = row_dot_short(b_rp, b_col, b_val, z, i, is_long);
-        c = row_dot_short(c_rp, c_col, c_val, z, i, is_long);
-        // the satisfiability gate (snark.cpp:121-124) for this row, here where its three values are in registers: a kernel of its own over
-        // the stored vectors stood 14 us (8 payloads) ... 53 us (37) in front of the transforms.  Rows with a long side: k_r1cs_check_rows.
-        if (flag && !is_long && a * b != c) or_and_wait(flag);
-    } else if (i <= (size_t)C + l) {
-        a = z[i - C];
-    }
-    aA[i] = a.normalized(); aB[i] = b.normalized(); aC[i] = c.normalized();
-}
-// long rows: entry = (matrix << 30) | row; one wavefront each
-__global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_t n_long,
-                                                    const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
-                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
-                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
-                                                    const Fr *z, Fr *aA, Fr *aB, Fr *aC) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_long) return;
-    uint32_t e = list[wave], mtx = e >> 30, row = e & 0x3fffffffu;
+// one wavefront per long row entry ((matrix << 30) | row): lanes stride over the terms, shuffle reduction
+ZK_D void r1cs_long_entry(uint32_t e, uint32_t lane, const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val, const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
+                          const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val, const Fr *z, Fr *aA, Fr *aB, Fr *aC) {
+    const uint32_t mtx = e >> 30, row = e & 0x3fffffffu;
     const uint32_t *rp = mtx == 0 ? a_rp : mtx == 1 ? b_rp : c_rp, *col = mtx == 0 ? a_col : mtx == 1 ? b_col : c_col;
     const Fr *val = mtx == 0 ? a_val : mtx == 1 ? b_val : c_val;
     Fr acc = Fr::zero();
@@ -222,6 +196,49 @@ __global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_
         acc += o;
     }
     if (lane == 0) (mtx == 0 ? aA : mtx == 1 ? aB : aC)[row] = acc.normalized();
+}
+// flag (or null): the satisfiability gate for rows without a long side, see below.  long_list (or null): the long row entries are filled in
+// by the first `long_blocks` workgroups of the SAME launch — they read z only and write what the others leave alone — instead of
+// by a launch of their own behind this one (k_r1cs_long: 12 ... 33 us and a launch boundary in front of the transforms).
+__global__ __launch_bounds__(256) void k_r1cs_eval(const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
+                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
+                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
+                                                    const Fr *z, uint32_t C, uint32_t l, size_t m, Fr *aA, Fr *aB, Fr *aC, int critical, uint32_t *flag /* or null */,
+                                                    const uint32_t *long_list /* or null */, uint32_t n_long, uint32_t long_blocks) {
+    crit_wave_priority(critical);
+    if (blockIdx.x < long_blocks) {                                          // (first in the grid: their chains start with the launch, not at its tail)
+        const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (wave < n_long) r1cs_long_entry(long_list[wave], threadIdx.x & 63, a_rp, a_col, a_val, b_rp, b_col, b_val, c_rp, c_col, c_val, z, aA, aB, aC);
+        return;
+    }
+    size_t i = (size_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
+    bool la = false, lb = false, lc = false;
+    if (i < C) {
+        a = row_dot_short(a_rp, a_col, a_val, z, i, la);
+        b = row_dot_short(b_rp, b_col, b_val, z, i, lb);
+        c = row_dot_short(c_rp, c_col, c_val, z, i, lc);
+        // the satisfiability gate (snark.cpp:121-124) for this row, here where its three values are in registers: a kernel of its own over
+        // the stored vectors stood 14 us (8 payloads) ... 53 us (37) in front of the transforms.  Rows with a long side: k_r1cs_check_rows.
+        if (flag && !(la | lb | lc) && a * b != c) or_and_wait(flag);
+    } else if (i <= (size_t)C + l) {
+        a = z[i - C];
+    }
+    const bool keep_long = long_list != nullptr;                             // the long sides belong to the launch's first workgroups
+    if (!(keep_long && la)) aA[i] = a.normalized();
+    if (!(keep_long && lb)) aB[i] = b.normalized();
+    if (!(keep_long && lc)) aC[i] = c.normalized();
+}
+// long rows as a launch of their own (ZKG_CHECK_KERNEL=1: the round-3 sequence eval, long, check)
+__global__ __launch_bounds__(256) void k_r1cs_long(const uint32_t *list, uint32_t n_long,
+                                                    const uint32_t *a_rp, const uint32_t *a_col, const Fr *a_val,
+                                                    const uint32_t *b_rp, const uint32_t *b_col, const Fr *b_val,
+                                                    const uint32_t *c_rp, const uint32_t *c_col, const Fr *c_val,
+                                                    const Fr *z, Fr *aA, Fr *aB, Fr *aC) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_long) return;
+    r1cs_long_entry(list[wave], lane, a_rp, a_col, a_val, b_rp, b_col, b_val, c_rp, c_col, c_val, z, aA, aB, aC);
 }
 // flag[0] |= 1 when a row violates <A,z><B,z> = <C,z>: the pb.is_satisfied() gate of snark.cpp:121-124.  The last workgroup to finish
 // (ticket in flag[1]) writes the verdict straight into the caller's pinned word: no copy launch between the mat-vec and the transforms.
@@ -386,12 +403,19 @@ static int compute_h_matvec(zkg_crs *crs, ProverSlot &S, const WitnessSrc &W, bo
                                     S.up_tags.as<uint8_t>(), S.wtags.as<uint8_t>(), S.wlisted.as<uint32_t>(), count, words, subset_pos, S.flag_host);
     }
     if (S.ev_ok) (void)hipEventRecord(S.ev[0], s);                      // z = [1 | w] is resident and split from here on
-    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s,
+    // ZKG_LONG_MERGED=1: the long rows' workgroups lead k_r1cs_eval's grid instead of being a launch of their own.  The stage gets shorter (8 payloads
+    // 0.069 -> 0.055 ms, 37 payloads 0.18 -> 0.13) and the proof does not: at 8 payloads it gets LONGER (1.13 -> 1.15 ms, three alternating runs) — the
+    // witness jobs' first small kernels used to slip onto the chip during the short launches in front of the first transform, and now find
+    // its workgroups holding every CU's LDS — and at 37 payloads it is inside the noise (3.06 against 3.08).  Off.
+    static const bool long_merged = getenv("ZKG_LONG_MERGED") != nullptr;
+    const unsigned eval_blocks = (unsigned)((m + 255) / 256), long_blocks = (fused_check && long_merged) ? (crs->n_long + 3) / 4 : 0;
+    hipLaunchKernelGGL(k_r1cs_eval, dim3(eval_blocks + long_blocks), dim3(256), 0, s,
                        crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                        crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
                        crs->Cm.rowptr.as<uint32_t>(), crs->Cm.col.as<uint32_t>(), crs->Cm.val.as<Fr>(),
-                       z, crs->C, crs->l, m, aA, aB, aC, crit, (want_flag && fused_check) ? words : nullptr);
-    if (crs->n_long)
+                       z, crs->C, crs->l, m, aA, aB, aC, crit, (want_flag && fused_check) ? words : nullptr,
+                       long_blocks ? crs->long_rows.as<uint32_t>() : nullptr, crs->n_long, long_blocks);
+    if (crs->n_long && !long_blocks)
         hipLaunchKernelGGL(k_r1cs_long, dim3((crs->n_long + 3) / 4), dim3(256), 0, s, crs->long_rows.as<uint32_t>(), crs->n_long,
                            crs->A.rowptr.as<uint32_t>(), crs->A.col.as<uint32_t>(), crs->A.val.as<Fr>(),
                            crs->B.rowptr.as<uint32_t>(), crs->B.col.as<uint32_t>(), crs->B.val.as<Fr>(),
