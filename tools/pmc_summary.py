@@ -36,7 +36,7 @@ bw = per_kernel(load(f"{src}/bench_WRITE_SIZE/*/*counter_collection.csv"))
 out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-cpu-baseline --no-extras --headline-only --steps 3 --warmup 1",
        "calibration": {"gather64_true_over_reported": round(gather_factor, 4), "stream16_true_over_reported": round(stream_factor, 4),
                        "store16_true_over_reported": round(store_factor, 4),
-                       "note": "FETCH_SIZE of k_bucket_accum29 is corrected with the 64-B gather factor (its reads are 80-B record gathers, five 16-B loads per lane, plus a 4-B/lane index stream)"},
+                       "note": "FETCH_SIZE of k_bucket_accum29 is corrected with the 64-B gather factor (its reads are 64-B record gathers, four 16-B loads per lane, plus a 4-B/lane index stream)"},
        "kernels": {}}
 for k in sorted(set(bf) | set(bw)):
     if not k.startswith("zk::"):

@@ -115,7 +115,7 @@ static constexpr int MSM_MAX_SETS = 4;                      // base sets sharing
 // scalars stands for element i - index_sub of the set (the L query starts behind the constant and the public inputs); smaller i: no base.
 // remap (optional, device): element i of the scalars stands for entry remap[i] of the set — a table that holds only a subset of the key's
 // elements (the prover's witness tables cover the non-bit variables only).
-// p29 (optional, G1 only): the same points, every level, as the 80-byte 29-bit records of fq29.hip.hpp (window_table_records29): a launch of
+// p29 (optional, G1 only): the same points, every level, as the 64-byte packed 29-bit records (Rec64) of fq29.hip.hpp (window_table_records29): a launch of
 // this set alone, without gather / remap / index_sub, then accumulates on the 29-bit representation without converting anything per call.
 struct MsmBases { const void *p = nullptr; bool g2 = false; size_t level_stride = 0; uint32_t index_sub = 0; const uint32_t *remap = nullptr; const void *p29 = nullptr; };
 // CSR matrices A, B, C handed from a circuit to the key generator without a copy

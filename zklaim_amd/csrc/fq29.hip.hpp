@@ -266,9 +266,54 @@ ZK_D Fq29 inverse(const Fq29 &a) {
 
 }  // namespace f29
 
-// a base point as the accumulation kernel gathers it: x, y as digits of x R', y R' (18 words), a flag word (1 = infinity) and padding to
-// 80 bytes, so that a point is five aligned 16-byte loads
-struct alignas(16) Affine29 { uint32_t x[9], y[9], inf, pad; };
+// a base point as the accumulation kernel holds it: x, y as digits of x R', y R' (18 words) and a flag word (1 = infinity)
+struct alignas(16) Affine29 { uint32_t x[9], y[9], inf, pad; };              // a base as the accumulation holds it in registers
+// ... and as it lies in memory: x R' and y R' (digits below 1.01 p: 255 bits) packed into 8 words each, the infinity flag in the top bit of
+// x's last word — ONE 64-byte line per base.  The 80-byte form (the struct above stored as it is) straddled two lines, sometimes three, and
+// the accumulation gathers a record per addition: a per-window table of 2^20 points is read at random, 16.8 M times per H query.
+struct alignas(64) Rec64 { uint32_t xw[8], yw[8]; };
+namespace f29 {
+ZK_D void pack8(const Fq29 &t, uint32_t (&w)[8]) {                           // digits -> 32-bit words (as from29 does behind its product)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const int i = (32 * l) / 29, s = 32 * l - 29 * i;
+        uint32_t v = t.v[i] >> s;
+        if (i + 1 < 9) v |= t.v[i + 1] << (29 - s);
+        if (s > 26 && i + 2 < 9) v |= t.v[i + 2] << (58 - s);
+        w[l] = v;
+    }
+}
+ZK_D void unpack8(const uint32_t (&w)[8], uint32_t (&v)[9]) {                // 32-bit words -> digits; bit 255 is not part of the value
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, l = bit >> 5, s = bit & 31;
+        uint32_t lo = w[l] >> s;
+        if (s > 3 && l + 1 < 8) lo |= w[l + 1] << (32 - s);
+        v[i] = i < 8 ? lo & Fq29::M : lo & 0x7fffffu;
+    }
+}
+}  // namespace f29
+ZK_D void store_rec64(Rec64 *dst, const Fq29 &x, const Fq29 &y, bool inf) {
+    Rec64 o;
+    f29::pack8(x, o.xw); f29::pack8(y, o.yw);
+    if (inf) o.xw[7] |= 0x80000000u;
+    uint4 *d = reinterpret_cast<uint4 *>(dst); const uint4 *s = reinterpret_cast<const uint4 *>(&o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = s[j];
+}
+ZK_D Rec64 load_rec64_raw(const Rec64 *src) {                                // the four loads only: the caller unpacks when it USES the record, not when it asks for it
+    Rec64 o; uint4 *d = reinterpret_cast<uint4 *>(&o); const uint4 *s = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = s[j];
+    return o;
+}
+ZK_D Affine29 unpack_rec64(const Rec64 &o) {
+    Affine29 a;
+    f29::unpack8(o.xw, a.x); f29::unpack8(o.yw, a.y);
+    a.inf = o.xw[7] >> 31; a.pad = 0;
+    return a;
+}
+ZK_D Affine29 load_rec64(const Rec64 *src) { return unpack_rec64(load_rec64_raw(src)); }
 
 // XYZZ accumulator of the 29-bit path.  Value bounds kept between additions (units of p): X < 5.3, Y < 3.4, ZZ, ZZZ < 1.1; X and Y digits.
 struct XYZZ29 {

@@ -616,28 +616,17 @@ __global__ __launch_bounds__(256) void k_bucket_accum(const ViewSet<F> views, co
 }
 
 // ---- 6'. the same accumulation for a plain G1 base set on the 29-bit representation (fq29.hip.hpp): 10 products of 895 cycles instead of
-//      1173 and carry-free additions per mixed addition.  The bases are converted once per launch into 80-byte records (k_bases_to29: two
+//      1173 and carry-free additions per mixed addition.  The bases are converted once per launch into 64-byte packed records (Rec64, k_bases_to29: two
 //      products per point against the 160 the point costs in the loop); an accumulator is converted back when its bucket is written, so
 //      everything downstream (heavy parts, fold, reduction, host) sees the same XYZZ<Fq> buckets as before.
-__global__ __launch_bounds__(256) void k_bases_to29(const Affine<Fq> *in, size_t n, Affine29 *out) {
+__global__ __launch_bounds__(256) void k_bases_to29(const Affine<Fq> *in, size_t n, Rec64 *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Affine<Fq> a = in[i];
-    const Fq29 x = f29::to29(a.x), y = f29::to29(a.y);
-    Affine29 o;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) { o.x[j] = x.v[j]; o.y[j] = y.v[j]; }
-    o.inf = a.is_inf() ? 1u : 0u; o.pad = 0;
-    uint4 *dst = reinterpret_cast<uint4 *>(out + i); const uint4 *src = reinterpret_cast<const uint4 *>(&o);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) dst[j] = src[j];
+    store_rec64(out + i, f29::to29(a.x), f29::to29(a.y), a.is_inf());
 }
-ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
-    Affine29 o; const uint4 *src = reinterpret_cast<const uint4 *>(bases + (e >> 1)); uint4 *dst = reinterpret_cast<uint4 *>(&o);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) dst[j] = src[j];
-    return o;
-}
+ZK_D Affine29 load29(const Rec64 *bases, uint32_t e) { return load_rec64(bases + (e >> 1)); }
+ZK_D Rec64 load29_raw(const Rec64 *bases, uint32_t e) { return load_rec64_raw(bases + (e >> 1)); }
 // WAVES: wavefronts per SIMD the register allocation aims for (2: no spill in the loop; 3: 168 registers and a 232-byte spill frame)
 // ACC29_VGPRS: left to itself the allocator spends all 256 registers two wavefronts per SIMD allow (253 for OUT29: loop-invariant constants
 // parked in registers) and nothing else fits on the SIMD beside them.  Capped at 192 the addition's instruction stream is the same (2 281
@@ -649,7 +638,7 @@ ZK_D Affine29 load29(const Affine29 *bases, uint32_t e) {
 // (piece-wise multi-exponentiation, msm_g1_host_scalars): a lane continues its bucket's accumulator, an empty list leaves it alone, and a
 // heavy bucket's old value joins its parts in k_heavy_merge.
 template <int WAVES, bool OUT29>
-__global__ __launch_bounds__(256, WAVES) ZK_VGPR_CAP(ACC29_VGPRS) void k_bucket_accum29(const Affine29 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
+__global__ __launch_bounds__(256, WAVES) ZK_VGPR_CAP(ACC29_VGPRS) void k_bucket_accum29(const Rec64 *bases, size_t level_stride, uint32_t B, const uint32_t *sorted, const uint32_t *offsets, const uint32_t *order,
                                                          size_t lanes, void *buckets_, HeavyItem *items, HeavyBucket *heavy, uint32_t *counters, SetLayout L, int flags /* 1: resume, 2: critical path */) {
     crit_wave_priority(flags & 2);
     const int resume = flags & 1;
@@ -683,11 +672,12 @@ __global__ __launch_bounds__(256, WAVES) ZK_VGPR_CAP(ACC29_VGPRS) void k_bucket_
         // two loads deep: under the addition of entry k the base of entry k + 1 arrives (its address came from an index loaded one
         // addition earlier) and the index of entry k + 2 — neither the index nor the base is ever waited for right after it was requested
         uint32_t e = sorted[k], e_next = k + 1 < end ? sorted[k + 1] : 0;
-        Affine29 p = load29(bases, e);
+        Rec64 p = load29_raw(bases, e);                                         // (kept packed while in flight: unpacked when its addition starts)
         while (true) {
-            const Affine29 cur = p; const uint32_t ce = e;
+            const Rec64 curw = p; const uint32_t ce = e;
             ++k;
-            if (k < end) { e = e_next; p = load29(bases, e); if (k + 1 < end) e_next = sorted[k + 1]; }
+            if (k < end) { e = e_next; p = load29_raw(bases, e); if (k + 1 < end) e_next = sorted[k + 1]; }
+            const Affine29 cur = unpack_rec64(curw);
             if (!cur.inf) {
                 Fq29 bx, by;
 #pragma unroll
@@ -1256,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(XYZZ<F> *partials_all, uin
 // ---- jobs: one MSM (or several base sets over one scalar vector) in flight on one stream ---------------------
 struct MsmGroup {                   // the base sets of one field in a launch: accumulators and the host landing zone of their chunk results
     DevBuf buckets, folded, red_out, heavy_items, heavy_buckets, heavy_counters, heavy_partials;
-    DevBuf bases29;                                    // a plain G1 set's bases as 80-byte 29-bit records (k_bases_to29), rebuilt per launch
+    DevBuf bases29;                                    // a plain G1 set's bases as 64-byte packed 29-bit records (Rec64, k_bases_to29), rebuilt per launch
     DevBuf ba_start, ba_pre, ba_planes;                // batched-affine levels (msm_ba.inc): bucket-start bits, prefix-product scratch, the levels' coordinate planes
     void *host_red = nullptr; size_t host_cap = 0; bool g2 = false, table = false; int nsets = 0;
     int out_index[MSM_MAX_SETS] = {0};                 // position of each set among the launch's sets of this field
@@ -1346,21 +1336,21 @@ static int launch_accumulate(MsmJob *job, MsmGroup &gr, const MsmBases *sets, co
     for (unsigned i = 0; i < ns; ++i) plain = plain && sets[i].level_stride == 0 && sets[i].index_sub == 0 && !sets[i].remap;
     // a plain G1 set takes the 29-bit accumulation (ZKG_ACCUM_32: the 8 x 32-bit kernel, kept for A/B runs and for several sets per launch)
     static const bool accum32 = getenv("ZKG_ACCUM_32") != nullptr;
-    bool use29 = false; const Affine29 *rec29 = nullptr; size_t stride29 = 0;
+    bool use29 = false; const Rec64 *rec29 = nullptr; size_t stride29 = 0;
     if constexpr (sizeof(F) == sizeof(Fq)) {
         if (ns == 1 && !accum32 && plain) {
             use29 = true;
-            if (sets[0].p29) rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29);       // the caller made the records (a piece of a piece-wise job)
+            if (sets[0].p29) rec29 = reinterpret_cast<const Rec64 *>(sets[0].p29);       // the caller made the records (a piece of a piece-wise job)
             else {
                 if (job->converted_aside) ZK_HIP(hipStreamWaitEvent(s, job->ev_join, 0));   // converted beside the sort (msm_job_launch)
                 else {
-                    if (gr.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
-                    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Affine29>());
+                    if (gr.bases29.reserve(n * sizeof(Rec64))) return ZKG_ERROR;
+                    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const Affine<Fq> *>(sets[0].p), n, gr.bases29.as<Rec64>());
                 }
-                rec29 = gr.bases29.as<Affine29>();
+                rec29 = gr.bases29.as<Rec64>();
             }
         } else if (ns == 1 && !accum32 && !d_gather && sets[0].p29 && !sets[0].remap && sets[0].index_sub == 0) {
-            use29 = true; rec29 = reinterpret_cast<const Affine29 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
+            use29 = true; rec29 = reinterpret_cast<const Rec64 *>(sets[0].p29); stride29 = sets[0].level_stride;      // a resident table's records
         }
     }
     static const bool red32_env = getenv("ZKG_REDUCE_32") != nullptr;
@@ -1724,10 +1714,10 @@ int msm_job_launch(MsmJob *job, const MsmBases *sets, int nsets, const uint32_t 
         if (!accum32 && !inline29 && !any_table && !d_gather && g1.nsets == 1 && by_field[0][0].index_sub == 0 && !by_field[0][0].remap && !by_field[0][0].p29) {
             if (!job->aux && (hipStreamCreateWithFlags(&job->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&job->ev_fork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&job->ev_join, hipEventDisableTiming) != hipSuccess)) { set_error("msm: side stream"); return ZKG_ERROR; }
-            if (g1.bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+            if (g1.bases29.reserve(n * sizeof(Rec64))) return ZKG_ERROR;
             ZK_HIP(hipEventRecord(job->ev_fork, job->stream));
             ZK_HIP(hipStreamWaitEvent(job->aux, job->ev_fork, 0));
-            hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, job->aux, reinterpret_cast<const Affine<Fq> *>(by_field[0][0].p), n, g1.bases29.as<Affine29>());
+            hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, job->aux, reinterpret_cast<const Affine<Fq> *>(by_field[0][0].p), n, g1.bases29.as<Rec64>());
             ZK_HIP(hipEventRecord(job->ev_join, job->aux));
             job->converted_aside = true;
         }
@@ -1866,10 +1856,10 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
     // all bases as 29-bit records, once (k_bases_to29 on the job's side stream: it runs under the first piece's upload)
     if (!J.aux && (hipStreamCreateWithFlags(&J.aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&J.ev_fork, hipEventDisableTiming) != hipSuccess ||
                    hipEventCreateWithFlags(&J.ev_join, hipEventDisableTiming) != hipSuccess)) { set_error("msm: side stream"); return ZKG_ERROR; }
-    if (J.group[0].bases29.reserve(n * sizeof(Affine29))) return ZKG_ERROR;
+    if (J.group[0].bases29.reserve(n * sizeof(Rec64))) return ZKG_ERROR;
     ZK_HIP(hipEventRecord(J.ev_fork, s));                                     // behind whatever the caller queued (the work that made the bases), and the last call's accumulation
     ZK_HIP(hipStreamWaitEvent(J.aux, J.ev_fork, 0));
-    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, J.aux, reinterpret_cast<const Affine<Fq> *>(d_bases), n, J.group[0].bases29.as<Affine29>());
+    hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, J.aux, reinterpret_cast<const Affine<Fq> *>(d_bases), n, J.group[0].bases29.as<Rec64>());
     ZK_HIP(hipEventRecord(J.ev_join, J.aux));
     ZK_HIP(hipStreamWaitEvent(s, J.ev_join, 0));
     if (s_hi) ZK_HIP(hipStreamWaitEvent(s_hi, J.ev_fork, 0));
@@ -1882,7 +1872,7 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
         const int which = (two_jobs && ((P - 1 - k) & 1)) ? 1 : 0;            // the last piece is the default job's: it carries the reduction and the result
         MsmJob &W = which ? K : J;
         MsmBases piece = set; piece.p = reinterpret_cast<const char *>(d_bases) + cut[k] * sizeof(G1Affine);
-        piece.p29 = J.group[0].bases29.as<Affine29>() + cut[k];
+        piece.p29 = J.group[0].bases29.as<Rec64>() + cut[k];
         W.resume = started; W.defer_reduce = k + 1 < P; started = true;
         W.sort_stream = s_hi;
         hipStream_t ss = s_hi ? s_hi : s;
@@ -1925,8 +1915,8 @@ int window_table_build_g1(WindowTable &t, const G1Affine *d_bases, size_t n, int
 int window_table_records29(WindowTable &t, hipStream_t s) {
     if (t.g2) { set_error("window_table_records29: G1 tables only"); return ZKG_ERROR; }
     const size_t total = t.n * (size_t)t.W;
-    if (t.rec29.reserve(std::max<size_t>(1, total) * sizeof(Affine29))) return ZKG_ERROR;
-    if (total) hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t.buf.as<Affine<Fq>>(), total, t.rec29.as<Affine29>());
+    if (t.rec29.reserve(std::max<size_t>(1, total) * sizeof(Rec64))) return ZKG_ERROR;
+    if (total) hipLaunchKernelGGL(k_bases_to29, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t.buf.as<Affine<Fq>>(), total, t.rec29.as<Rec64>());
     if (hipGetLastError() != hipSuccess) { set_error("window table records launch failed"); return ZKG_ERROR; }
     return ZKG_OK;
 }
