@@ -97,6 +97,7 @@ struct NttPassArgs29 {
     uint32_t n_log, s0, R, cw_log, first, last, has_post_scalar, row_pad;      // row_pad: records of padding per LDS row
     uint32_t xcd_tiles;                                                        // tiles per XCD (0 = identity map)
     uint32_t critical;                                                         // raise the wavefronts' issue priority (crit_wave_priority)
+    uint32_t norm_stores;                                                      // radix-4 steps: carry propagation on the four stores (round 3) instead of on the two added-to loads
     size_t src_batch_stride, dst_batch_stride;      // elements between the vectors of a batch (blockIdx.y), in the units of src / dst
 };
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass29(NttPassArgs29 A) {
@@ -199,16 +200,28 @@ __global__ __launch_bounds__(256) void k_ntt_pass29_r4(NttPassArgs29 A) {
             const uint32_t lo = A.first ? 0u : ((tile * CW + c) & lo_mask);
             const size_t eb = ((size_t)((j << A.s0) + lo)) << (A.n_log - 2 - s);              // stage s + 1, row bits j
             const Fr29 wb = fr29::load_rec(A.tw + eb), wc = fr29::load_rec(A.tw + eb + ((size_t)1 << (A.n_log - 2)));   // ... and row bits j + h: (h << s0) << (n - 2 - s) = N / 4 further
-            const Fr29 x0 = fr29::load_rec(p0), x2 = fr29::load_rec(p2);
+            // Records in LDS and between passes hold LAZY limbs (below 2.5 x 2^30, see the bounds above): the two rows that only get added to
+            // (x0, x2) are carried here, on load; the two that get multiplied (x1, x3) go into the product as they are — two carry
+            // propagations per butterfly instead of four on the stores (ZKG_NTT_NORM_STORES=1: the old placement, for A/B).
+            Fr29 x0 = fr29::load_rec(p0), x2 = fr29::load_rec(p2);
+            if (!A.norm_stores) { x0 = fr29::norm(x0); x2 = fr29::norm(x2); }
             Fr29 t1 = fr29::load_rec(p1), t3 = fr29::load_rec(p3);
             if (s != 0) { const Fr29 wa = fr29::load_rec(A.tw + 2 * eb); fr29::mul2(t1, t3, t1, wa, t3, wa); }
+            else if (!A.norm_stores) { t1 = fr29::norm(t1); t3 = fr29::norm(t3); }      // (stage 0 has no product to bring them back to digits)
             const Fr29 y0 = fr29::add_lazy(x0, t1), y1 = fr29::sub_lazy(x0, t1), y2 = fr29::add_lazy(x2, t3), y3 = fr29::sub_lazy(x2, t3);
             Fr29 u2, u3;
             fr29::mul2(u2, u3, y2, wb, y3, wc);
-            fr29::store_rec(p0, fr29::norm(fr29::add_lazy(y0, u2)));
-            fr29::store_rec(p2, fr29::norm(fr29::sub_lazy(y0, u2)));
-            fr29::store_rec(p1, fr29::norm(fr29::add_lazy(y1, u3)));
-            fr29::store_rec(p3, fr29::norm(fr29::sub_lazy(y1, u3)));
+            if (A.norm_stores) {
+                fr29::store_rec(p0, fr29::norm(fr29::add_lazy(y0, u2)));
+                fr29::store_rec(p2, fr29::norm(fr29::sub_lazy(y0, u2)));
+                fr29::store_rec(p1, fr29::norm(fr29::add_lazy(y1, u3)));
+                fr29::store_rec(p3, fr29::norm(fr29::sub_lazy(y1, u3)));
+            } else {
+                fr29::store_rec(p0, fr29::add_lazy(y0, u2));
+                fr29::store_rec(p2, fr29::sub_lazy(y0, u2));
+                fr29::store_rec(p1, fr29::add_lazy(y1, u3));
+                fr29::store_rec(p3, fr29::sub_lazy(y1, u3));
+            }
         }
         __syncthreads();
     }
@@ -217,13 +230,13 @@ __global__ __launch_bounds__(256) void k_ntt_pass29_r4(NttPassArgs29 A) {
         for (uint32_t bf = tid; bf < (rows >> 1) * CW; bf += nthr) {
             uint32_t c = bf & (CW - 1), k = bf >> A.cw_log;
             uint32_t j = k & (half - 1), r0 = ((k >> q) << (q + 1)) | j, r1 = r0 + half;
-            const Fr29 u = fr29::load_rec(lds + r0 * stride + c);
+            const Fr29 u = fr29::norm(fr29::load_rec(lds + r0 * stride + c));                 // (lazy limbs in: see the radix-4 steps)
             Fr29 v = fr29::load_rec(lds + r1 * stride + c);
             if (s != 0) {
                 uint32_t lo = A.first ? 0u : ((tile * CW + c) & lo_mask);
                 size_t e = ((size_t)((j << A.s0) + lo)) << (A.n_log - 1 - s);
                 v = fr29::mul(v, fr29::load_rec(A.tw + e));
-            }
+            } else v = fr29::norm(v);
             fr29::store_rec(lds + r0 * stride + c, fr29::add_norm(u, v));
             fr29::store_rec(lds + r1 * stride + c, fr29::sub_norm(u, v));
         }
@@ -410,6 +423,8 @@ int ntt_run_ex(NttDomain *d, Fr *d_a, bool inverse, const Fr *pre, const Fr *pos
             // the transforms are the prover's critical path at 2^20 (beside the witness multi-exponentiations); below, the G2 witness chain ends
             // as late as the H query and raised priorities here cost more there (CRIT_PRIORITY_MIN_LOG)
             B.critical = crit_priority_for(2, n) ? 1u : 0u;
+            static const bool norm_stores = getenv("ZKG_NTT_NORM_STORES") != nullptr;                                  // A/B switch
+            B.norm_stores = norm_stores ? 1u : 0u;
             static const int radix_force = getenv("ZKG_NTT_RADIX2") ? (atoi(getenv("ZKG_NTT_RADIX2")) ? 2 : 4) : 0;          // A/B switch
             if (radix_force ? radix_force == 4 : large) {
                 const unsigned threads4 = (unsigned)std::min<size_t>(256, std::max<size_t>(64, rows * CW / 4));             // one thread per four rows of a column
