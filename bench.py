@@ -504,7 +504,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_bucket_accum29", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                      "kernel_ms": round(kern_ms, 4), "launches": launches, "launches_per_step": round(launches / max(1, args.steps), 2),
-                     "kernel_ms_note": "the accumulation's launches of ONE step added up (the piece-wise step launches it once per piece), HIP events on the launch stream",
+                     "kernel_ms_note": "the accumulation's launches of ONE step added up (the piece-wise step launches it once per piece), HIP events on the launch stream around every launch of every fourth step of the timed region (their records cost the stream 2 % of a step when every launch carries them; ZKG_KERNEL_TIMER_STRIDE=1)",
                      "note": "integer-VALU-bound kernel (10 Montgomery products of 9 x 29-bit limbs per 96 input bytes and window); see DESIGN.md"},
     }
     if kern_ms > 0:

@@ -310,8 +310,10 @@ int zkg_g1_add_quad29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, in
 /* the same for the pair form the bucket reduction uses since round 4 (xyzz29_add_pair: lane 0 of a pair holds (X, ZZ), lane 1 (Y, ZZZ)) */
 int zkg_g1_add_pair29(const uint64_t *a_jac, const uint64_t *b_jac, size_t n, int chain, uint64_t *out_jac);
 
-/* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on):
- * average device ms per launch of the dominant kernel over the calls since the last reset */
+/* kernel-only timing hooks for bench.py (HIP events on the stream the kernels run on): average device ms per launch of the dominant kernel
+ * since the last reset.  Every fourth call of an MSM entry point is timed, with all of its launches (the event records cost the stream they
+ * sit on: 2 % of a 2^20-point step when every launch carries them; ZKG_KERNEL_TIMER_STRIDE=1 times every call); *launches is the launch
+ * count of ALL calls since the reset, so that average x launches / calls is the kernel's time per call. */
 void  zkg_timing_reset(void);
 float zkg_timing_dominant_ms(int *launches);
 

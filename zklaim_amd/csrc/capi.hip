@@ -45,9 +45,16 @@ bool crit_priority_for(int part, unsigned log_m) {
 }
 static std::mutex g_timer_mu;
 static constexpr size_t TIMER_MAX_PAIRS = 4096;              // a long-running host that never drains the timer stops recording here
+void KernelTimer::new_call() {
+    static const size_t stride = getenv("ZKG_KERNEL_TIMER_STRIDE") ? (size_t)std::max(1, atoi(getenv("ZKG_KERNEL_TIMER_STRIDE"))) : 4;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    sample = (calls++ % stride) == 0;
+    ++calls_seen; if (sample) ++calls_timed;
+}
 void KernelTimer::begin(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_timer_mu);
     pending = false;
+    if (!sample) return;
     static const bool off = getenv("ZKG_KERNEL_TIMER") && atoi(getenv("ZKG_KERNEL_TIMER")) == 0;      // A/B switch: what the two event records per launch cost the step
     if (off || !enabled || used >= TIMER_MAX_PAIRS) return;
     // (timing only: no system-scope fence — the write-back of whatever the kernel before left dirty would be timed and would delay the kernel behind)
@@ -68,10 +75,10 @@ float KernelTimer::drain(int *launches) {
         float ms = 0;
         if (hipEventSynchronize(pairs[i].second) == hipSuccess && hipEventElapsedTime(&ms, pairs[i].first, pairs[i].second) == hipSuccess) { total += ms; ++n; }
     }
-    if (launches) *launches = n;
+    if (launches) *launches = calls_timed ? (int)((size_t)n * calls_seen / calls_timed) : n;
     return n ? total / n : 0.f;
 }
-void KernelTimer::reset() { std::lock_guard<std::mutex> lk(g_timer_mu); used = 0; pending = false; }
+void KernelTimer::reset() { std::lock_guard<std::mutex> lk(g_timer_mu); used = 0; pending = false; calls = 0; calls_seen = 0; calls_timed = 0; sample = true; }
 
 // ---- host thread pool -------------------------------------------------------------------------------------
 namespace {

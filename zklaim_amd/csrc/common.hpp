@@ -37,8 +37,14 @@ struct ScopedDevBuf : DevBuf {
 // HIP-event timing of the dominant kernel (bench.py's roofline.achieved), on the launch stream
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs; size_t used = 0; bool enabled = true, pending = false;
+    // The two event records around a launch are not free on the stream they sit on (traced: the four accumulation launches of a 2^20-point
+    // step lose 38 us to them, 2 % of the step), so only every `stride`-th CALL of an entry point is timed — all of its launches, so that the
+    // pieces of a piece-wise call weigh what they weigh — and drain() scales the launch count back up (ZKG_KERNEL_TIMER_STRIDE, default 4; 1: all).
+    size_t calls = 0, calls_seen = 0, calls_timed = 0; bool sample = true;
+    void new_call();                  // an entry point that launches the dominant kernel starts (under its job's mutex)
     void begin(hipStream_t s); void end(hipStream_t s);
-    float drain(int *launches);       // average ms since last reset (synchronises the events)
+    float drain(int *launches);       // average ms per launch over the timed calls since the last reset (synchronises the events); *launches: the
+                                      // launches of ALL calls since then (timed launches x calls / timed calls)
     void reset();
 };
 extern KernelTimer g_dominant_timer;

@@ -1760,6 +1760,7 @@ int msm_shared(const G1Affine *const *d_g1_bases, int n_g1, const G2Affine *d_g2
                bool scalars_mont, G1 *out_g1, G2 *out_g2, hipStream_t s, uint32_t w0, uint32_t ws, bool mostly_bits) {
     if (n_g1 < 0 || n_g1 + (d_g2_bases ? 1 : 0) > MSM_MAX_SETS) { set_error("msm: too many base sets"); return ZKG_ERROR; }
     std::lock_guard<std::mutex> lk(g_default_job.mu);
+    g_dominant_timer.new_call();
     g_default_job.stream = s; g_default_job.w0 = w0; g_default_job.ws = ws ? ws : 1; g_default_job.one_pass_sort = mostly_bits;
     MsmBases sets[MSM_MAX_SETS]; int nsets = 0;
     for (int i = 0; i < n_g1; ++i) { sets[nsets] = MsmBases(); sets[nsets].p = d_g1_bases[i]; ++nsets; }
@@ -1809,6 +1810,7 @@ int msm_g1_host_scalars(const G1Affine *d_bases, const uint32_t *h_scalars, size
     }
     MsmJob &J = g_default_job;
     std::lock_guard<std::mutex> lk(J.mu);
+    g_dominant_timer.new_call();
     if (J.hs_scalars.reserve(n * 32)) return ZKG_ERROR;
     if (!J.copy) {
         if (hipStreamCreateWithFlags(&J.copy, hipStreamNonBlocking) != hipSuccess) { J.copy = nullptr; set_error("msm: copy stream"); return ZKG_ERROR; }
