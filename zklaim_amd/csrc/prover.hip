@@ -726,6 +726,8 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     // below in several steps, and a failure between them (a device allocation under memory pressure) must leave a state the next proof
     // recognises — count == 0 sends it back here — instead of old tables under a new position map.
     T.count = 0;
+    const auto t_ext0 = std::chrono::steady_clock::now();
+    auto ext_lap = [&](const char *w) { if (g_dbg_timing) fprintf(stderr, "[zkg]       subset_extend %-28s %8.3f ms\n", w, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_ext0).count()); };
     std::vector<uint32_t> li(listed);
     ZK_HIP(hipMemcpyAsync(li.data(), S.wlisted.p, listed * 4, hipMemcpyDeviceToHost, s));
     ZK_HIP(hipStreamSynchronize(s));
@@ -735,6 +737,7 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
     idx.reserve(listed + T.count);
     for (size_t i = 0; i < n1; ++i) if (T.member[i]) { pos[i] = (uint32_t)idx.size(); idx.push_back((uint32_t)i); }
     const size_t count = idx.size();
+    ext_lap("listed read, positions built");
     if (T.pos.reserve(n1 * 4) || T.idx.reserve(count * 4 + 16)) return ZKG_ERROR;
     ZK_HIP(hipMemcpyAsync(T.pos.p, pos.data(), n1 * 4, hipMemcpyHostToDevice, s));
     ZK_HIP(hipMemcpyAsync(T.idx.p, idx.data(), count * 4, hipMemcpyHostToDevice, s));
@@ -764,6 +767,7 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
                          hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__);
         stage.release(); stage2.release();
         if (!got) return ZKG_ERROR;
+        ext_lap("points gathered and read back");
         const int c = c_new, W = (254 + c) / c;                               // = (SCALAR_BITS + c - 1) / c of window_table_build
         std::vector<G1Affine> t1((size_t)3 * W * count); std::vector<G2Affine> t2((size_t)W * count);
         auto levels = [&](auto base, auto *out /* level w of this point at out[w * count] */) {
@@ -787,6 +791,7 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
             const size_t tb = (size_t)task / count, i = (size_t)task % count;
             if (tb < 3) levels(p1[tb * count + i], &t1[tb * (size_t)W * count + i]); else levels(p2[i], &t2[i]);
         });
+        ext_lap("levels on the host pool");
         WindowTable *g1t[3] = {&T.A, &T.B1, &T.L};
         bool up = true;
         for (int tb = 0; tb < 3 && up; ++tb) {
@@ -799,6 +804,7 @@ static int subset_extend(zkg_crs *crs, ProverSlot &S, size_t listed) {
              hip_ok(hipMemcpyAsync(T.B2.buf.p, t2.data(), (size_t)W * count * sizeof(G2Affine), hipMemcpyHostToDevice, s), "H2D", __FILE__, __LINE__);
         up = hip_ok(hipStreamSynchronize(s), "sync", __FILE__, __LINE__) && up;          // (host vectors go out of scope)
         if (!up) return ZKG_ERROR;
+        ext_lap("tables uploaded");
         crs->c_w = c_new; T.count = count; ++T.rebuilds;
         if (g_dbg_timing) fprintf(stderr, "[zkg]     witness tables over %zu of %zu elements (rebuild %u, levels on the host)\n", count, n1, T.rebuilds);
         return ZKG_OK;
