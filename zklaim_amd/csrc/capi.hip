@@ -139,6 +139,18 @@ struct Pool {
             if (r) drain(*r);
         }
     }
+    bool try_run(int count, const std::function<void(int)> &f) {              // the pool's turn if it is free; false (nothing done) if it is busy
+        if (workers.empty()) return false;
+        std::unique_lock<std::mutex> rl(run_mu, std::defer_lock);
+        if (!rl.try_lock()) return false;
+        auto r = std::make_shared<Run>(); r->fn = f; r->n = count;
+        { std::lock_guard<std::mutex> lk(mu); cur = r; ++epoch; epoch_a.store(epoch, std::memory_order_release); }
+        cv_work.notify_all();
+        drain(*r);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return r->done.load() == r->n; });
+        return true;
+    }
     void run(int count, const std::function<void(int)> &f, bool wait_for_pool) {
         if (count <= 1 || workers.empty()) { for (int i = 0; i < count; ++i) f(i); return; }
         // the pool runs one loop at a time; a caller that finds it busy (the seam's key-digest thread hashing 200 MB, say) does its own
@@ -164,6 +176,20 @@ void host_parallel_for(int n, const std::function<void(int)> &fn) { host_pool().
 bool host_pool_prewake_enabled() { static const bool on = getenv("ZKG_POOL_PREWAKE") && atoi(getenv("ZKG_POOL_PREWAKE")) != 0; return on; }
 void host_pool_prewake(unsigned spin_us) { if (host_pool_prewake_enabled()) host_pool().prewake(spin_us); }
 void host_parallel_for_wait(int n, const std::function<void(int)> &fn) { host_pool().run(n, fn, true); }
+// heavy loops (tens of milliseconds of work: a credential circuit's synthesis with its constraints) that find the pool busy — the key loader hashing and
+// parsing a blob, in the same first libsnark_prove — neither run inline (28 ms on one thread instead of 5) nor queue behind it: they get threads of
+// their own for the call.  Creating them costs ~0.3 ms; not for the short loops of a proof's latency path.
+void host_parallel_for_spawn(int n, const std::function<void(int)> &fn) {
+    if (n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    if (host_pool().try_run(n, fn)) return;
+    const int nt = std::min(n, 15);
+    std::atomic<int> next{0};
+    std::vector<std::thread> th; th.reserve((size_t)nt);
+    auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+    for (int t = 0; t < nt - 1; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
 
 // ---- ABI point encodings -----------------------------------------------------------------------
 static void put(uint64_t *out, const Fq &a) { memcpy(out, a.v, 32); }

@@ -56,6 +56,7 @@ void host_parallel_for(int n, const std::function<void(int)> &fn);
 bool host_pool_prewake_enabled();                 // ZKG_POOL_PREWAKE=1
 void host_pool_prewake(unsigned spin_us);      // the caller will call host_parallel_for within spin_us: wake the workers now, let them poll for it
 void host_parallel_for_wait(int n, const std::function<void(int)> &fn);
+void host_parallel_for_spawn(int n, const std::function<void(int)> &fn);   // the pool if it is free, threads of its own if not (heavy loops only)
 
 // ---------------- NTT (ntt.hip) ----------------
 struct NttDomain {

@@ -573,18 +573,6 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = f
         }
     }
     lap("queries up, H table built");
-    // the constraint system last: the blob path parses it on another thread while the GPU decompresses the points and builds the table
-    if (ok && constraint_system_ready && !constraint_system_ready()) ok = false;
-    ok = ok && upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
-         upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
-    if (ok) {                                                                // rows left to the wavefront-per-row kernel
-        std::vector<uint32_t> lr;
-        const uint32_t *rps[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr};
-        for (uint32_t mtx = 0; mtx < 3; ++mtx)
-            for (uint32_t r = 0; r < crs->C; ++r) if (rps[mtx][r + 1] - rps[mtx][r] > LONG_ROW) lr.push_back((mtx << 30) | r);
-        crs->n_long = (uint32_t)lr.size();
-        ok = crs->C < (1u << 30) && upload(crs->long_rows, lr.data(), lr.size() * 4) == 0;
-    }
     if (ok) {
         memcpy(&crs->alpha_g1, pk->alpha_g1, 64); memcpy(&crs->beta_g1, pk->beta_g1, 64); memcpy(&crs->delta_g1, pk->delta_g1, 64);
         memcpy(&crs->beta_g2, pk->beta_g2, 128); memcpy(&crs->delta_g2, pk->delta_g2, 128);
@@ -604,6 +592,21 @@ static zkg_crs *zkg_crs_upload_impl(const zkg_pk *pk, bool queries_on_device = f
     lap("comb tables + domain");
     ok = ok && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__) && slot_create(crs, crs->slot[0]) == ZKG_OK;
     lap("prover slot created");
+    // the constraint system last — behind the comb tables, the domain and the prover slot, which do not need it: the blob path parses it on another
+    // thread meanwhile (8 payloads: the parse ends 2.4 ms after the H table stands; what used to follow it was 4.8 ms, now 1.2)
+    if (ok && constraint_system_ready && !constraint_system_ready()) ok = false;
+    ok = ok && upload_csr(crs->A, cs.a_rowptr, cs.a_col, cs.a_val, crs->C) == 0 && upload_csr(crs->B, cs.b_rowptr, cs.b_col, cs.b_val, crs->C) == 0 &&
+         upload_csr(crs->Cm, cs.c_rowptr, cs.c_col, cs.c_val, crs->C) == 0;
+    if (ok) {                                                                // rows left to the wavefront-per-row kernel
+        std::vector<uint32_t> lr;
+        const uint32_t *rps[3] = {cs.a_rowptr, cs.b_rowptr, cs.c_rowptr};
+        for (uint32_t mtx = 0; mtx < 3; ++mtx)
+            for (uint32_t r = 0; r < crs->C; ++r) if (rps[mtx][r + 1] - rps[mtx][r] > LONG_ROW) lr.push_back((mtx << 30) | r);
+        crs->n_long = (uint32_t)lr.size();
+        ok = crs->C < (1u << 30) && upload(crs->long_rows, lr.data(), lr.size() * 4) == 0;
+    }
+    ok = ok && hip_ok(hipDeviceSynchronize(), "sync", __FILE__, __LINE__);
+    lap("constraint system up");
     if (!ok) { zkg_crs_free(crs); return nullptr; }
     return crs;
 }

@@ -208,7 +208,8 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
         const uint32_t first = pb.extend((size_t)per * np);
         std::vector<char> bad(np, 0);
         std::vector<Builder> views(np);
-        host_parallel_for((int)np, [&](int t) {
+        // (with constraints recorded this is the heavy loop of a first libsnark_prove, beside the key loader: threads of its own if the pool is taken)
+        (pb.recording ? host_parallel_for_spawn : host_parallel_for)((int)np, [&](int t) {
             Builder &v = views[t];
             v = Builder::view_of(pb, first + (uint32_t)t * per, first + (uint32_t)(t + 1) * per);
             if (v.recording) { v.cons.reserve(cons_per); v.arena.reserve(terms_per); }
@@ -226,7 +227,7 @@ static zkg_circuit *build_zklaim(const zklaim_ctx *ctx, bool with_witness, bool 
     if (pb.recording) {
         Builder::Csr *ms[3] = {&ck->A, &ck->B, &ck->C};
         const int chunks = getenv("ZKG_SERIAL_CIRCUIT") ? 1 : (int)std::min<size_t>(16, pb.cons.size() / 8192 + 1);
-        pb.export_csr_chunked(ms, chunks, [](int tasks, const std::function<void(int)> &f) { host_parallel_for(tasks, f); });
+        pb.export_csr_chunked(ms, chunks, [](int tasks, const std::function<void(int)> &f) { host_parallel_for_spawn(tasks, f); });
     }
     lap("CSR exported");
     ck->has_witness = with_witness;             // the witness is pb.val[1..] itself: Fr is the ABI's 4 x u64 Montgomery element
