@@ -884,6 +884,7 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
     // for the split (event 0), reads it and queues the four witness streams' work while this thread queues the critical path.
     auto witness_fn = [&]() -> int {
         ZK_HIP(hipEventSynchronize(S.ev[0]));
+        lap(S, "  (helper) split landed");
         const size_t listed = S.flag_host[1];
         if (S.flag_host[3]) { set_error("prover: a listed witness index is out of range, not tagged 2 or listed twice"); return ZKG_ERROR; }
         if (listed > n + 1) { set_error("prover: witness split out of range"); return ZKG_ERROR; }
@@ -914,17 +915,20 @@ static int prove_enqueue(zkg_crs *crs, ProverSlot &S, const WitnessSrc &witness,
             hipStream_t js = msm_job_stream(S.job_w2);                         // G2 first: the longest chains
             ZK_HIP(hipStreamWaitEvent(S.stream_o, go, 0));
             if (ones_sum_launch(S.ones_g2, &o2, 1, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            lap(S, "  (helper) G2 ones-sum enqueued");
             (void)hipEventRecord(S.ev[10], S.stream_o);                        // the G2 sum has landed (the G1 sums follow on the same stream)
             if (g_serial_msm) (void)hipStreamSynchronize(S.stream_o);          // (profiling aid: the flat sum alone on the chip, then the job's kernels)
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[6], js);
             if (msm_job_launch(S.job_w2, &b2, 1, z, listed, true, gather)) return ZKG_ERROR;
+            lap(S, "  (helper) G2 job enqueued");
             (void)hipEventRecord(S.ev[7], js);
             if (g_serial_msm) { (void)hipStreamSynchronize(S.stream_o); (void)hipStreamSynchronize(js); }
         }
         {
             hipStream_t js = msm_job_stream(S.job_w1);
             if (ones_sum_launch(S.ones_g1, o1, 3, tags, n + 1, S.stream_o)) return ZKG_ERROR;
+            lap(S, "  (helper) G1 ones-sums enqueued");
             if (g_serial_msm) (void)hipStreamSynchronize(S.stream_o);
             ZK_HIP(hipStreamWaitEvent(js, go, 0));
             (void)hipEventRecord(S.ev[4], js);
