@@ -13,7 +13,7 @@ def load(pat):
     return list(csv.DictReader(open(glob.glob(pat)[0])))
 
 
-CALLS = 4          # tools/pmc_collect.sh runs bench.py --headline-only --steps 3 --warmup 1: every launch belongs to one of these 4 steps
+CALLS = 6          # tools/pmc_collect.sh runs bench.py --headline-only --steps 3 --warmup 1: every launch belongs to one of these 4 steps or to bench.py's 2 setup calls
 
 
 def per_kernel(rows):
